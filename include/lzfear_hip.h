@@ -1,0 +1,154 @@
+/*
+ * lzfear_hip.h — C ABI of the MI355X (gfx950) LZ4 raw-block codec that drops in under
+ * lz-fear's `raw` module.
+ *
+ * This is the boundary a Rust `-sys` crate would bind (INTEGRATION.md shows the `extern "C"`
+ * block and the safe wrappers with the reference's own signatures).  Plain pointers and sizes
+ * only; no C++ or torch types.  Each entry point cites the reference interface it replaces
+ * (file:line in the lz-fear 0.2.0 tree).
+ *
+ * The reference calls its codec once per frame block (src/framed/compress.rs:243,
+ * src/framed/decompress.rs:248).  The GPU boundary is the same call *batched over jobs*: one
+ * job = one `compress2` / `decompress_raw` invocation, one wavefront (compress) or one
+ * workgroup (decompress) each, many jobs per launch.
+ *
+ * Memory: every pointer in a job is a DEVICE pointer (HBM) unless the function name ends in
+ * `_host`.  The library never retains pointers past a call and owns no global state besides
+ * lazily created scratch for the `_host` helpers.  There is NO CPU fallback: every entry point
+ * returns LZF_E_NO_DEVICE when no HIP device is usable.
+ */
+#ifndef LZFEAR_HIP_H
+#define LZFEAR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LZFEAR_ABI_VERSION 1
+
+/* ---- per-job status (lzf_job_result.status) --------------------------------------------- */
+enum {
+    LZF_OK = 0,
+    /* raw::DecodeError — src/raw/decompress.rs:8-17 */
+    LZF_UNEXPECTED_END = 1,
+    LZF_MEMORY_LIMIT_EXCEEDED = 2,
+    LZF_ZERO_DEDUP_OFFSET = 3,
+    LZF_INVALID_DEDUP_OFFSET = 4,
+    /* compress2's writer refused a write: io::ErrorKind::ConnectionAborted from
+     * NoPartialWrites — src/framed/compress.rs:294-314, matched at :250-255 */
+    LZF_OUTPUT_FULL = 5,
+    /* the reference would panic: assert at src/raw/compress/mod.rs:167, expect at :67/:92 */
+    LZF_CONTRACT = 6,
+    /* decode output buffer smaller than what the reference's Vec would have grown to
+     * (literals are not limit-checked, src/raw/decompress.rs:63-67): give the job
+     * out_cap >= output_limit + input_len and this never happens */
+    LZF_OUT_CAPACITY = 7
+};
+
+/* ---- library-level return codes (negative) ---------------------------------------------- */
+enum {
+    LZF_E_NO_DEVICE = -1,     /* no HIP device / HIP runtime error at init */
+    LZF_E_HIP = -2,           /* a HIP call failed; lzf_last_error() has the text */
+    LZF_E_INVALID = -3        /* bad argument (NULL jobs with n_jobs > 0, ...) */
+};
+
+/* ---- encoder tables: src/raw/compress/mod.rs:27-36 (U32Table), :78-87 (U16Table) --------- */
+#define LZF_TABLE_U32 0       /* 4096 x u32, payload limit u32::MAX (:75)  — what framed uses (:202) */
+#define LZF_TABLE_U16 1       /* 8192 x u16, payload limit 65535   (:100) — raw API only        */
+
+typedef struct lzf_u32_table { uint32_t dict[4096]; uint64_t offset; } lzf_u32_table;
+typedef struct lzf_u16_table { uint16_t dict[8192]; uint64_t offset; } lzf_u16_table;
+
+/* ---- jobs ------------------------------------------------------------------------------- */
+
+/* One `compress2(input, cursor, &mut table, writer)` call — src/raw/compress/mod.rs:165-166.
+ *   input[0..cursor) is addressable history (dictionary / previous-block window),
+ *   input[cursor..input_len) is the payload.  The writer is a bounded sink of `out_cap` bytes
+ *   with NoPartialWrites semantics (the frame layer passes out_cap = payload length,
+ *   src/framed/compress.rs:242).
+ *   table == NULL  <=>  `&mut T::default()` thrown away afterwards (independent blocks without
+ *   a dictionary).  Otherwise it points at an lzf_u32_table / lzf_u16_table in device memory
+ *   which is read at start and written back at the end (mutations survive LZF_OUTPUT_FULL,
+ *   exactly like the reference's `&mut table`). */
+typedef struct lzf_compress_job {
+    const uint8_t* input;
+    uint64_t input_len;
+    uint64_t cursor;
+    uint8_t* out;
+    uint64_t out_cap;
+    void* table;
+    uint32_t table_kind;          /* LZF_TABLE_U32 | LZF_TABLE_U16 */
+    uint32_t flags;               /* LZF_CJOB_* */
+} lzf_compress_job;
+
+#define LZF_CJOB_TABLE_READONLY 1u   /* do not write the table back: `template_table.clone()`
+                                        per independent block, src/framed/compress.rs:220,270 */
+
+/* One `decompress_raw(input, prefix, &mut output, output_limit)` call —
+ * src/raw/decompress.rs:58-59.  `out[0..out_existing_len)` is the Vec's content on entry
+ * (addressable history); decoded bytes are appended after it.  out_cap is the room the Vec may
+ * grow to. */
+typedef struct lzf_decompress_job {
+    const uint8_t* input;
+    uint64_t input_len;
+    const uint8_t* prefix;
+    uint64_t prefix_len;
+    uint8_t* out;
+    uint64_t out_existing_len;
+    uint64_t out_cap;
+    uint64_t output_limit;
+} lzf_decompress_job;
+
+typedef struct lzf_job_result {
+    uint64_t out_len;             /* compress: bytes written; decompress: output.len() (incl. existing) */
+    int32_t status;               /* LZF_OK ... LZF_OUT_CAPACITY; out_len is unspecified on error */
+    uint32_t reserved;
+} lzf_job_result;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int lzf_abi_version(void);
+const char* lzf_last_error(void);
+/* Number of usable HIP devices (>= 1) or LZF_E_NO_DEVICE. */
+int lzf_device_count(void);
+
+/* Batched raw::compress2 — src/raw/compress/mod.rs:165-238 for every job.
+ * d_jobs / d_results are device arrays of n_jobs entries.  Asynchronous on `hip_stream`
+ * (a hipStream_t; NULL = the legacy default stream) of the CURRENT device.
+ * `table_kinds` says which table types occur in the batch (the job array lives in HBM, the
+ * host cannot look): LZF_KINDS_U32, LZF_KINDS_U16 or both or'ed; 0 means "either". */
+#define LZF_KINDS_U32 1u
+#define LZF_KINDS_U16 2u
+int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results,
+                       uint32_t n_jobs, uint32_t table_kinds, void* hip_stream);
+
+/* Batched raw::decompress_raw — src/raw/decompress.rs:58-138 for every job. */
+int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_results,
+                         uint32_t n_jobs, void* hip_stream);
+
+/* EncoderTable helpers on device tables.
+ * lzf_table_seed_from_dictionary: the template-table loop of src/framed/compress.rs:202-211
+ *   (`for window in dict.windows(8).step_by(3) { template_table.replace(dict, offset) }`).
+ * lzf_table_offset: EncoderTable::offset — src/raw/compress/mod.rs:72-74 / :97-99. */
+int lzf_table_seed_from_dictionary(lzf_u32_table* d_table, const uint8_t* d_dict,
+                                   uint64_t dict_len, void* hip_stream);
+int lzf_table_offset(void* d_table, uint32_t table_kind, uint64_t add, void* hip_stream);
+
+/* Batched XXH32 (seed 0) of n device buffers: the per-block checksums of
+ * src/framed/compress.rs:259-263 and src/framed/decompress.rs:228-235. */
+int lzf_xxh32_batch(const uint8_t* const* d_ptrs, const uint64_t* d_lens, uint32_t* d_out,
+                    uint32_t n, void* hip_stream);
+
+/* ---- host-buffer convenience (synchronous; stages through device scratch) ---------------
+ * Same semantics as the batch calls but every pointer in the jobs is a HOST pointer and
+ * `results` is a host array.  `table` pointers are host lzf_*_table structs, updated in
+ * place.  Used by the frame layer and by callers that have not moved their data to HBM. */
+int lzf_compress_batch_host(const lzf_compress_job* jobs, lzf_job_result* results, uint32_t n_jobs);
+int lzf_decompress_batch_host(const lzf_decompress_job* jobs, lzf_job_result* results, uint32_t n_jobs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LZFEAR_HIP_H */

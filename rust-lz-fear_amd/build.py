@@ -1,0 +1,44 @@
+"""Build recipe for liblzfear_hip.so (hipcc, gfx950 only).  In-tree output so that the
+library travels with the repo snapshot to the GPU box."""
+import os
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+ROOT = os.path.dirname(PKG_DIR)
+LIB_PATH = os.path.join(PKG_DIR, "liblzfear_hip.so")
+
+HIP_SOURCES = ["capi.hip", "lz4_decompress.hip", "lz4_compress.hip", "aux_kernels.hip"]
+CXX_SOURCES = []
+DEPS = HIP_SOURCES + CXX_SOURCES + ["kernels.h", "lzf_device.h", os.path.join(ROOT, "include", "lzfear_hip.h")]
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    for d in DEPS:
+        p = d if os.path.isabs(d) else os.path.join(CSRC, d)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def hipcc():
+    for c in ("/opt/rocm/bin/hipcc", "hipcc"):
+        if os.path.isabs(c) and os.path.exists(c):
+            return c
+    return "hipcc"
+
+
+def build_library(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> rust-lz-fear_amd/liblzfear_hip.so"""
+    if not force and not _stale():
+        return LIB_PATH
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH]
+    cmd += [os.path.join(CSRC, s) for s in HIP_SOURCES + CXX_SOURCES]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH

@@ -1,0 +1,78 @@
+// aux_kernels.hip — small kernels around the codec: XXH32 of many buffers, dictionary
+// seeding of a U32Table, EncoderTable::offset.
+#include "lzf_device.h"
+
+namespace lzf {
+
+// ---------------------------------------------------------------------------------------
+// XXH32 (seed 0) — the block checksums of src/framed/compress.rs:259-263 and
+// src/framed/decompress.rs:228-235 (twox-hash XxHash32).  The four accumulators of one hash
+// are four adjacent lanes; a wave hashes 16 buffers at a time.  Each accumulator is a serial
+// multiply-rotate chain over its stripe words, so parallelism is 4 lanes x #buffers.
+// ---------------------------------------------------------------------------------------
+constexpr uint32_t XP1 = 2654435761u, XP2 = 2246822519u, XP3 = 3266489917u, XP4 = 668265263u, XP5 = 374761393u;
+__device__ __forceinline__ uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+__device__ __forceinline__ uint32_t xround(uint32_t acc, uint32_t w) { return rotl32(acc + w * XP2, 13) * XP1; }
+
+__global__ __launch_bounds__(64) void lzf_xxh32_kernel(const uint8_t* const* __restrict__ ptrs,
+                                                       const uint64_t* __restrict__ lens,
+                                                       uint32_t* __restrict__ out, uint32_t n) {
+    const uint32_t g = (blockIdx.x * 64u + threadIdx.x) >> 2;
+    const uint32_t q = threadIdx.x & 3u;
+    const bool act = g < n;
+    const uint8_t* p = act ? ptrs[g] : nullptr;
+    const uint64_t len = act ? lens[g] : 0;
+    uint32_t v = q == 0 ? XP1 + XP2 : q == 1 ? XP2 : q == 2 ? 0u : 0u - XP1;
+    const uint64_t stripes = len >> 4;
+    const uint8_t* sp = p + q * 4u;
+    uint64_t s = 0;
+    for (; s + 4 <= stripes; s += 4) {   // 4 loads in flight per lane
+        const uint32_t w0 = ld4(sp + (s + 0) * 16), w1 = ld4(sp + (s + 1) * 16);
+        const uint32_t w2 = ld4(sp + (s + 2) * 16), w3 = ld4(sp + (s + 3) * 16);
+        v = xround(xround(xround(xround(v, w0), w1), w2), w3);
+    }
+    for (; s < stripes; ++s) v = xround(v, ld4(sp + s * 16));
+    // merge the four accumulators (lanes 4g..4g+3)
+    const uint32_t r = q == 0 ? rotl32(v, 1) : q == 1 ? rotl32(v, 7) : q == 2 ? rotl32(v, 12) : rotl32(v, 18);
+    uint32_t h = r + __shfl_xor(r, 1);
+    h = h + __shfl_xor(h, 2);
+    if (act && q == 0) {
+        if (len < 16) h = XP5;   // seed + PRIME5
+        h += (uint32_t)len;
+        const uint8_t* t = p + (stripes << 4);
+        uint32_t rem = (uint32_t)(len & 15u);
+        while (rem >= 4) { h = rotl32(h + ld4(t) * XP3, 17) * XP4; t += 4; rem -= 4; }
+        while (rem) { h = rotl32(h + (uint32_t)(*t) * XP5, 11) * XP1; ++t; --rem; }
+        h ^= h >> 15; h *= XP2; h ^= h >> 13; h *= XP3; h ^= h >> 16;
+        out[g] = h;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Template-table seeding — src/framed/compress.rs:202-211:
+//   for window in dict.windows(8).step_by(3) { template_table.replace(dict, offset) }
+// on a default table.  Sequential semantics = "the last position with a given hash wins", and
+// positions only grow, so the result is a per-slot maximum: order-free atomicMax.
+// (Slot value 0 means both "empty" and "position 0", exactly as in the reference, mod.rs:34.)
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lzf_seed_table_kernel(lzf_u32_table* __restrict__ t,
+                                                             const uint8_t* __restrict__ dict, uint64_t dict_len) {
+    if (dict_len < 8) return;
+    const uint64_t count = (dict_len - 8) / 3 + 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t o = i * 3;
+        const uint64_t v8 = ld8(dict + o);
+        const uint32_t h = (uint32_t)(((v8 << 24) * 889523592379ull) >> 52);
+        atomicMax(&t->dict[h], (uint32_t)o);
+    }
+}
+
+// EncoderTable::offset — src/raw/compress/mod.rs:72-74 (U32Table), :97-99 (U16Table)
+__global__ void lzf_table_offset_kernel(void* table, uint32_t kind, uint64_t add) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (kind == LZF_TABLE_U32) ((lzf_u32_table*)table)->offset += add;
+        else ((lzf_u16_table*)table)->offset += add;
+    }
+}
+
+}  // namespace lzf

@@ -1,0 +1,211 @@
+// capi.hip — the extern "C" boundary declared in include/lzfear_hip.h.
+// Plain HIP runtime calls + kernel launches; no CPU codec anywhere in this file: without a
+// usable HIP device every entry point fails with LZF_E_NO_DEVICE.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail_hip(hipError_t e, const char* what) {
+    char buf[256];
+    snprintf(buf, sizeof buf, "%s: %s", what, hipGetErrorString(e));
+    g_last_error = buf;
+    return LZF_E_HIP;
+}
+#define HIP_TRY(expr)                                          \
+    do {                                                       \
+        hipError_t e__ = (expr);                               \
+        if (e__ != hipSuccess) return fail_hip(e__, #expr);    \
+    } while (0)
+
+int ensure_device() {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        g_last_error = "no HIP device available (the lz-fear HIP codec has no CPU fallback)";
+        (void)hipGetLastError();
+        return LZF_E_NO_DEVICE;
+    }
+    return n;
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// RAII device buffer for the *_host helpers
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 1); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+}  // namespace
+
+extern "C" {
+
+int lzf_abi_version(void) { return LZFEAR_ABI_VERSION; }
+const char* lzf_last_error(void) { return g_last_error.c_str(); }
+int lzf_device_count(void) { return ensure_device(); }
+
+int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results, uint32_t n_jobs,
+                       uint32_t table_kinds, void* hip_stream) {
+    if (n_jobs == 0) return LZF_OK;
+    if (!d_jobs || !d_results) { g_last_error = "lzf_compress_batch: NULL job/result array"; return LZF_E_INVALID; }
+    int rc = ensure_device();
+    if (rc < 0) return rc;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    if (table_kinds == 0) table_kinds = LZF_KINDS_U32 | LZF_KINDS_U16;
+    if (table_kinds & LZF_KINDS_U32)
+        hipLaunchKernelGGL(lzf::lzf_compress_wave_kernel<LZF_TABLE_U32>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs);
+    if (table_kinds & LZF_KINDS_U16)
+        hipLaunchKernelGGL(lzf::lzf_compress_wave_kernel<LZF_TABLE_U16>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs);
+    HIP_TRY(hipGetLastError());
+    return LZF_OK;
+}
+
+int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n_jobs, void* hip_stream) {
+    if (n_jobs == 0) return LZF_OK;
+    if (!d_jobs || !d_results) { g_last_error = "lzf_decompress_batch: NULL job/result array"; return LZF_E_INVALID; }
+    int rc = ensure_device();
+    if (rc < 0) return rc;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipLaunchKernelGGL(lzf::lzf_decompress_wave_kernel, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs);
+    HIP_TRY(hipGetLastError());
+    return LZF_OK;
+}
+
+int lzf_table_seed_from_dictionary(lzf_u32_table* d_table, const uint8_t* d_dict, uint64_t dict_len, void* hip_stream) {
+    if (!d_table || (!d_dict && dict_len)) { g_last_error = "lzf_table_seed_from_dictionary: NULL argument"; return LZF_E_INVALID; }
+    if (dict_len > 0xFFFFFFFFull) { g_last_error = "dictionary beyond u32 positions (reference panics, mod.rs:67)"; return LZF_E_INVALID; }
+    int rc = ensure_device();
+    if (rc < 0) return rc;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    HIP_TRY(hipMemsetAsync(d_table, 0, sizeof(lzf_u32_table), st));   // U32Table::default()
+    if (dict_len >= 8) {
+        const uint64_t count = (dict_len - 8) / 3 + 1;
+        uint32_t blocks = (uint32_t)((count + 255) / 256);
+        if (blocks > 1024) blocks = 1024;
+        hipLaunchKernelGGL(lzf::lzf_seed_table_kernel, dim3(blocks), dim3(256), 0, st, d_table, d_dict, dict_len);
+        HIP_TRY(hipGetLastError());
+    }
+    return LZF_OK;
+}
+
+int lzf_table_offset(void* d_table, uint32_t table_kind, uint64_t add, void* hip_stream) {
+    if (!d_table || table_kind > LZF_TABLE_U16) { g_last_error = "lzf_table_offset: bad argument"; return LZF_E_INVALID; }
+    int rc = ensure_device();
+    if (rc < 0) return rc;
+    hipLaunchKernelGGL(lzf::lzf_table_offset_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(hip_stream), d_table, table_kind, add);
+    HIP_TRY(hipGetLastError());
+    return LZF_OK;
+}
+
+int lzf_xxh32_batch(const uint8_t* const* d_ptrs, const uint64_t* d_lens, uint32_t* d_out, uint32_t n, void* hip_stream) {
+    if (n == 0) return LZF_OK;
+    if (!d_ptrs || !d_lens || !d_out) { g_last_error = "lzf_xxh32_batch: NULL argument"; return LZF_E_INVALID; }
+    int rc = ensure_device();
+    if (rc < 0) return rc;
+    hipLaunchKernelGGL(lzf::lzf_xxh32_kernel, dim3((n + 15) / 16), dim3(64), 0, static_cast<hipStream_t>(hip_stream), d_ptrs, d_lens, d_out, n);
+    HIP_TRY(hipGetLastError());
+    return LZF_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// host-buffer helpers: stage -> launch -> copy back.  Synchronous.
+// ---------------------------------------------------------------------------------------
+int lzf_compress_batch_host(const lzf_compress_job* jobs, lzf_job_result* results, uint32_t n_jobs) {
+    if (n_jobs == 0) return LZF_OK;
+    if (!jobs || !results) { g_last_error = "lzf_compress_batch_host: NULL argument"; return LZF_E_INVALID; }
+    int rc = ensure_device();
+    if (rc < 0) return rc;
+    // layout of one staging slab: [inputs | outputs | tables]
+    std::vector<size_t> in_off(n_jobs), out_off(n_jobs), tab_off(n_jobs);
+    size_t total = 0;
+    uint32_t kinds = 0;
+    for (uint32_t i = 0; i < n_jobs; ++i) {
+        if (jobs[i].table_kind > LZF_TABLE_U16) { g_last_error = "bad table_kind"; return LZF_E_INVALID; }
+        kinds |= jobs[i].table_kind == LZF_TABLE_U32 ? LZF_KINDS_U32 : LZF_KINDS_U16;
+        in_off[i] = total; total = align_up(total + jobs[i].input_len, 256);
+    }
+    for (uint32_t i = 0; i < n_jobs; ++i) { out_off[i] = total; total = align_up(total + jobs[i].out_cap, 256); }
+    for (uint32_t i = 0; i < n_jobs; ++i) {
+        tab_off[i] = total;
+        if (jobs[i].table) total = align_up(total + sizeof(lzf_u32_table), 256);   // both table structs are 16392 B
+    }
+    static_assert(sizeof(lzf_u32_table) == sizeof(lzf_u16_table), "table structs share a slab slot size");
+    DevBuf slab, djobs, dres;
+    HIP_TRY(slab.alloc(total));
+    HIP_TRY(djobs.alloc(sizeof(lzf_compress_job) * n_jobs));
+    HIP_TRY(dres.alloc(sizeof(lzf_job_result) * n_jobs));
+    uint8_t* base = slab.as<uint8_t>();
+    std::vector<lzf_compress_job> dj(jobs, jobs + n_jobs);
+    for (uint32_t i = 0; i < n_jobs; ++i) {
+        if (jobs[i].input_len) HIP_TRY(hipMemcpy(base + in_off[i], jobs[i].input, jobs[i].input_len, hipMemcpyHostToDevice));
+        dj[i].input = base + in_off[i];
+        dj[i].out = base + out_off[i];
+        if (jobs[i].table) {
+            HIP_TRY(hipMemcpy(base + tab_off[i], jobs[i].table, sizeof(lzf_u32_table), hipMemcpyHostToDevice));
+            dj[i].table = base + tab_off[i];
+        }
+    }
+    HIP_TRY(hipMemcpy(djobs.p, dj.data(), sizeof(lzf_compress_job) * n_jobs, hipMemcpyHostToDevice));
+    rc = lzf_compress_batch(djobs.as<lzf_compress_job>(), dres.as<lzf_job_result>(), n_jobs, kinds, nullptr);
+    if (rc != LZF_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(results, dres.p, sizeof(lzf_job_result) * n_jobs, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n_jobs; ++i) {
+        if (results[i].status == LZF_OK && results[i].out_len)
+            HIP_TRY(hipMemcpy(jobs[i].out, base + out_off[i], results[i].out_len, hipMemcpyDeviceToHost));
+        if (jobs[i].table && !(jobs[i].flags & LZF_CJOB_TABLE_READONLY) && results[i].status != LZF_CONTRACT)
+            HIP_TRY(hipMemcpy(jobs[i].table, base + tab_off[i], sizeof(lzf_u32_table), hipMemcpyDeviceToHost));
+    }
+    return LZF_OK;
+}
+
+int lzf_decompress_batch_host(const lzf_decompress_job* jobs, lzf_job_result* results, uint32_t n_jobs) {
+    if (n_jobs == 0) return LZF_OK;
+    if (!jobs || !results) { g_last_error = "lzf_decompress_batch_host: NULL argument"; return LZF_E_INVALID; }
+    int rc = ensure_device();
+    if (rc < 0) return rc;
+    std::vector<size_t> in_off(n_jobs), pre_off(n_jobs), out_off(n_jobs);
+    size_t total = 0;
+    for (uint32_t i = 0; i < n_jobs; ++i) { in_off[i] = total; total = align_up(total + jobs[i].input_len, 256); }
+    for (uint32_t i = 0; i < n_jobs; ++i) { pre_off[i] = total; total = align_up(total + jobs[i].prefix_len, 256); }
+    for (uint32_t i = 0; i < n_jobs; ++i) { out_off[i] = total; total = align_up(total + jobs[i].out_cap, 256); }
+    DevBuf slab, djobs, dres;
+    HIP_TRY(slab.alloc(total));
+    HIP_TRY(djobs.alloc(sizeof(lzf_decompress_job) * n_jobs));
+    HIP_TRY(dres.alloc(sizeof(lzf_job_result) * n_jobs));
+    uint8_t* base = slab.as<uint8_t>();
+    std::vector<lzf_decompress_job> dj(jobs, jobs + n_jobs);
+    for (uint32_t i = 0; i < n_jobs; ++i) {
+        if (jobs[i].out_existing_len > jobs[i].out_cap) { g_last_error = "out_existing_len > out_cap"; return LZF_E_INVALID; }
+        if (jobs[i].input_len) HIP_TRY(hipMemcpy(base + in_off[i], jobs[i].input, jobs[i].input_len, hipMemcpyHostToDevice));
+        if (jobs[i].prefix_len) HIP_TRY(hipMemcpy(base + pre_off[i], jobs[i].prefix, jobs[i].prefix_len, hipMemcpyHostToDevice));
+        if (jobs[i].out_existing_len) HIP_TRY(hipMemcpy(base + out_off[i], jobs[i].out, jobs[i].out_existing_len, hipMemcpyHostToDevice));
+        dj[i].input = base + in_off[i];
+        dj[i].prefix = base + pre_off[i];
+        dj[i].out = base + out_off[i];
+    }
+    HIP_TRY(hipMemcpy(djobs.p, dj.data(), sizeof(lzf_decompress_job) * n_jobs, hipMemcpyHostToDevice));
+    rc = lzf_decompress_batch(djobs.as<lzf_decompress_job>(), dres.as<lzf_job_result>(), n_jobs, nullptr);
+    if (rc != LZF_OK) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(results, dres.p, sizeof(lzf_job_result) * n_jobs, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < n_jobs; ++i) {
+        uint64_t n = results[i].out_len;
+        if (n > jobs[i].out_cap) n = jobs[i].out_cap;
+        if (n > jobs[i].out_existing_len)
+            HIP_TRY(hipMemcpy(jobs[i].out + jobs[i].out_existing_len, base + out_off[i] + jobs[i].out_existing_len,
+                              n - jobs[i].out_existing_len, hipMemcpyDeviceToHost));
+    }
+    return LZF_OK;
+}
+
+}  // extern "C"

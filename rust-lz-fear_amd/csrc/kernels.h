@@ -1,0 +1,17 @@
+// kernels.h — declarations of the gfx950 kernels for the C-ABI translation unit.
+#pragma once
+#include "lzf_device.h"
+
+namespace lzf {
+__global__ void lzf_decompress_wave_kernel(const lzf_decompress_job* __restrict__ jobs,
+                                           lzf_job_result* __restrict__ results, uint32_t n_jobs);
+template <int KIND>
+__global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
+                                         lzf_job_result* __restrict__ results, uint32_t n_jobs);
+extern template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U32>(const lzf_compress_job*, lzf_job_result*, uint32_t);
+extern template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U16>(const lzf_compress_job*, lzf_job_result*, uint32_t);
+__global__ void lzf_xxh32_kernel(const uint8_t* const* __restrict__ ptrs, const uint64_t* __restrict__ lens,
+                                 uint32_t* __restrict__ out, uint32_t n);
+__global__ void lzf_seed_table_kernel(lzf_u32_table* __restrict__ t, const uint8_t* __restrict__ dict, uint64_t dict_len);
+__global__ void lzf_table_offset_kernel(void* table, uint32_t kind, uint64_t add);
+}  // namespace lzf

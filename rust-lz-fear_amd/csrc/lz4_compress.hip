@@ -1,0 +1,298 @@
+// lz4_compress.hip — batched raw::compress2 for gfx950 (MI355X), wave64, bit-exact.
+//
+// Replaces src/raw/compress/mod.rs:165-238 of lz-fear (compress2) together with its tables
+// (:27-101), count_matching_bytes (:117-145) and write_group / LSIC coding (:150-163,:239-260)
+// for many blocks per launch.  One wavefront compresses one block; the position table lives
+// in LDS (16 KiB for U32Table, 32 KiB for the U16Table variant).
+//
+// The reference parse is a strictly sequential state machine (greedy first match, single-slot
+// table, skip schedule); its output depends on the exact order of table updates.  The kernel
+// reproduces it with *speculative batches*: the 64 lanes evaluate the next 64 probe positions
+// of the skip schedule (closed form below) as if every earlier probe in the batch missed, and
+// the wave then commits exactly the prefix the sequential algorithm would have executed:
+//   1. lane k hashes input[c_k..c_k+8) and reads its table slot (the pre-batch value);
+//   2. same-slot collisions inside the batch are found by a min-lane tag written through the
+//      slot itself (ds_write MARK, ds_min lane, ds_read): lane k is "first" for its slot iff
+//      the tag equals k.  The batch is cut after the first lane D that is not first — its
+//      candidate is the position of the (unique) earlier lane with the same slot;
+//   3. the winner W is the first lane whose candidate passes the reference's accept test
+//      (mod.rs:200-206), or the first lane that hits the <12-bytes-left rule (:178);
+//   4. lanes <= W write their positions (the sequential `replace` calls that really happened),
+//      every other touched slot gets its pre-batch value back.
+// Match extension and backtracking (:204,:211-212) are wave-parallel compares + ballot.
+#include "lzf_device.h"
+
+namespace lzf {
+
+// S(m) = sum of the first m advances of one literal run (mod.rs:174-175,225-231):
+// advance after probe j is 1 for j <= 65, then (62 + j) >> 6.
+__device__ __forceinline__ uint32_t sched_prefix(uint32_t m) {
+    if (m <= 66u) return m;
+    const uint32_t r = m - 66u;
+    const uint32_t full = r >> 6, rem = r & 63u;
+    return 66u + 64u * (full * (full - 1u) / 2u + 2u * full) + rem * (full + 2u);
+}
+
+template <int KIND> struct TableTraits;
+template <> struct TableTraits<LZF_TABLE_U32> {
+    static constexpr uint32_t kSlots = 4096;
+    static constexpr uint64_t kLimit = 0xFFFFFFFFull;                 // mod.rs:75
+    // mod.rs:41-51: v = 8 bytes LE (0 if fewer than 8 remain), ((v << 24) * 889523592379) >> 52
+    static __device__ __forceinline__ uint32_t hash(uint64_t v8) {
+        return (uint32_t)(((v8 << 24) * 889523592379ull) >> 52);
+    }
+};
+template <> struct TableTraits<LZF_TABLE_U16> {
+    static constexpr uint32_t kSlots = 8192;
+    static constexpr uint64_t kLimit = 0xFFFFull;                     // mod.rs:100
+    // mod.rs:58-61: (u32 * 2654435761) >> 19
+    static __device__ __forceinline__ uint32_t hash(uint64_t v8) {
+        return ((uint32_t)v8 * 2654435761u) >> 19;
+    }
+};
+
+constexpr uint32_t kMark = 0xFFFFFFFFu;
+constexpr uint32_t kMaxLen = 0x7FFFFF00u;
+
+// Bounded sink with NoPartialWrites semantics (src/framed/compress.rs:294-314).
+struct Sink {
+    uint8_t* out;
+    uint32_t pos, cap;
+};
+
+// LSIC tail length in bytes (mod.rs:243-260): 0 if v < 15 else (v-15)/255 + 1.
+__device__ __forceinline__ uint32_t lsic_len(uint32_t v) { return v < 15u ? 0u : (v - 15u) / 255u + 1u; }
+
+__device__ __forceinline__ void lsic_store(uint8_t* dst, uint32_t v, uint32_t n, uint32_t lane) {
+    // n = lsic_len(v) > 0: n-1 bytes of 0xFF then (v-15) % 255
+    for (uint32_t i = lane; i < n; i += kWave) dst[i] = (i + 1u == n) ? (uint8_t)((v - 15u) % 255u) : (uint8_t)0xFF;
+}
+
+template <int KIND>
+__global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
+    const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs) {
+    using TT = TableTraits<KIND>;
+    __shared__ uint32_t tab[TT::kSlots];
+
+    const uint32_t jid = blockIdx.x;
+    if (jid >= n_jobs) return;
+    const uint32_t lane = threadIdx.x;
+    const lzf_compress_job job = jobs[jid];
+    if (job.table_kind != (uint32_t)KIND) return;   // handled by the other instantiation
+
+    const uint8_t* __restrict__ in = job.input;
+    int status = LZF_OK;
+    Sink s{job.out, 0u, job.out_cap > kMaxLen ? kMaxLen : (uint32_t)job.out_cap};
+    uint64_t base_off = 0;   // EncoderTable.offset (mod.rs:30,:81)
+
+    // ---- table in: Default::default() (:32-36) or the caller's table
+    if (job.table) {
+        if (KIND == LZF_TABLE_U32) {
+            const lzf_u32_table* t = (const lzf_u32_table*)job.table;
+            for (uint32_t i = lane; i < TT::kSlots; i += kWave) tab[i] = t->dict[i];
+            base_off = t->offset;
+        } else {
+            const lzf_u16_table* t = (const lzf_u16_table*)job.table;
+            for (uint32_t i = lane; i < TT::kSlots; i += kWave) tab[i] = t->dict[i];
+            base_off = t->offset;
+        }
+    } else {
+        for (uint32_t i = lane; i < TT::kSlots; i += kWave) tab[i] = 0u;
+    }
+
+    if (job.input_len > TT::kLimit || job.input_len >= kMaxLen || job.cursor > job.input_len) {
+        status = LZF_CONTRACT;                                           // mod.rs:167
+    } else {
+        const uint32_t len = (uint32_t)job.input_len;
+        const uint32_t init = (uint32_t)job.cursor;                      // :169
+        uint32_t cursor = init;
+        const uint32_t boff = (uint32_t)base_off;   // low 32 bits; overflow is checked at commit
+
+        while (cursor < len && status == LZF_OK) {                        // :171
+            const uint32_t ls = cursor;                                   // :172 literal_start
+            uint32_t n = 0;          // probe index inside this literal run
+            uint32_t c = cursor;     // position of probe n
+            bool finished = false;   // last-literals path taken
+            uint32_t m_pos = 0, m_cand = 0;   // winner
+
+            // ================= search: speculative batches of the :177-232 loop
+            for (;;) {
+                const uint32_t sn = sched_prefix(n);
+                const uint32_t ck = c + (sched_prefix(n + lane) - sn);
+                const bool endk = (ck > len) || (len - ck < 12u);         // :178
+                const bool active = !endk;
+                uint64_t v8 = 0;
+                if (active) v8 = ld8(in + ck);       // >= 12 bytes remain: the 8-byte read is in range
+                const uint32_t h = TT::hash(v8);
+                uint32_t old = 0, first = lane;
+                if (active) old = tab[h];
+                if (active) tab[h] = kMark;
+                if (active) atomicMin(&tab[h], lane);
+                if (active) first = tab[h];
+                const bool dup = active && first != lane;
+                const uint32_t D = first_lane(__ballot(dup));             // 64 = no collision
+                const uint32_t e_end = first_lane(__ballot(endk));
+                // candidate the sequential algorithm would see at lane k (k <= D)
+                uint32_t cand;
+                {
+                    const uint64_t stored = old;
+                    cand = stored > base_off ? (uint32_t)(stored - base_off) : 0u;   // :70 saturating_sub
+                    const uint32_t c_first = __shfl(ck, (int)(first & 63u));
+                    if (lane == D) cand = c_first;
+                }
+                bool valid = false;
+                if (active && lane <= D && ck != init && cand <= ck && ck - cand <= 0xFFFFu) {   // :200-201
+                    valid = ld4(in + cand) == (uint32_t)v8;               // :204-206 (m >= 4)
+                }
+                const uint32_t W = first_lane(__ballot(valid));
+                // last lane whose `replace` really executed in sequential order (+1)
+                uint32_t commit_end;   // lanes [0, commit_end) commit
+                int outcome;           // 0 = continue, 1 = match at W, 2 = end of input
+                if (W < e_end && W <= D) { commit_end = W + 1u; outcome = 1; }
+                else if (D < 64u) { commit_end = D + 1u; outcome = 0; }
+                else if (e_end < 64u) { commit_end = e_end; outcome = 2; }
+                else { commit_end = 64u; outcome = 0; }
+                // EncoderTable contract (:67/:92): position + offset must fit the slot type
+                {
+                    const bool bad = active && lane < commit_end && ((uint64_t)ck + base_off > TT::kLimit);
+                    if (__ballot(bad)) { status = LZF_CONTRACT; }
+                }
+                // ---- commit / roll back
+                if (active) {
+                    if (lane < commit_end) {
+                        // lane first[D] is overridden by D when D commits
+                        const uint32_t fD = __shfl(first, (int)(D & 63u));
+                        const bool overridden = (D < commit_end) && (lane == fD) && (lane != D);
+                        if (!overridden) tab[h] = ck + boff;
+                    } else if (first >= commit_end) {
+                        tab[h] = old;
+                    }
+                }
+                if (status != LZF_OK) break;
+                if (outcome == 1) {
+                    m_pos = __shfl(ck, (int)W);
+                    m_cand = __shfl(cand, (int)W);
+                    break;
+                }
+                if (outcome == 2) { finished = true; break; }
+                n += commit_end;
+                c += sched_prefix(n) - sn;
+            }
+            if (status != LZF_OK) break;
+
+            if (finished) {
+                // ---- last literals, mod.rs:178-190
+                const uint32_t L = len - ls;
+                const uint32_t nl = lsic_len(L);
+                const uint32_t total = 1u + nl + L;
+                if (s.cap - s.pos < total) {
+                    // which individual write fails does not matter: the sink content is dropped
+                    status = LZF_OUTPUT_FULL;
+                    break;
+                }
+                uint8_t* d = s.out + s.pos;
+                if (lane == 0) d[0] = (uint8_t)((L < 15u ? L : 15u) << 4);
+                if (nl) lsic_store(d + 1, L, nl, lane);
+                wave_copy(d + 1u + nl, in + ls, L, lane);
+                s.pos += total;
+                cursor = len;
+                break;
+            }
+
+            // ================= match found at m_pos against m_cand (distance checked)
+            // forward extension: common prefix of input[m_pos .. len-5) and input[m_cand ..) (:195,:203-204)
+            const uint32_t alen = (len - 5u) - m_pos;
+            uint32_t m = 4u;   // first 4 bytes already known equal
+            {
+                const uint8_t* a = in + m_pos;
+                const uint8_t* b = in + m_cand;
+                bool done = false;
+                while (!done && alen - m >= 512u) {              // 8 bytes per lane
+                    const uint64_t x = ld8(a + m + lane * 8u) ^ ld8(b + m + lane * 8u);
+                    const unsigned long long neq = __ballot(x != 0ull);
+                    if (neq) {
+                        const uint32_t fl = (uint32_t)__builtin_ctzll(neq);
+                        const uint64_t xf = __shfl(x, (int)fl);
+                        m += fl * 8u + (uint32_t)(__builtin_ctzll(xf) >> 3);
+                        done = true;
+                    } else {
+                        m += 512u;
+                    }
+                }
+                while (!done) {                                   // 1 byte per lane
+                    const uint32_t i = m + lane;
+                    const bool inr = i < alen;
+                    bool ne = true;
+                    if (inr) ne = a[i] != b[i];
+                    const unsigned long long neq = __ballot(ne);   // out-of-range lanes stop the scan
+                    if (neq) { m += (uint32_t)__builtin_ctzll(neq); done = true; }
+                    else m += 64u;
+                }
+            }
+            // backtrack (:211-212): at most (m_pos - ls) and at most m_cand bytes
+            uint32_t bt = 0;
+            {
+                const uint32_t maxbt = (m_pos - ls) < m_cand ? (m_pos - ls) : m_cand;
+                bool done = maxbt == 0u;
+                while (!done) {
+                    const uint32_t i = bt + lane;
+                    bool ne = true;
+                    if (i < maxbt) ne = in[m_pos - 1u - i] != in[m_cand - 1u - i];
+                    const unsigned long long neq = __ballot(ne);
+                    if (neq) { bt += (uint32_t)__builtin_ctzll(neq); done = true; }
+                    else bt += 64u;
+                }
+            }
+            const uint32_t dup_offset = m_pos - m_cand;                    // :208
+            const uint32_t extra = m - 4u + bt;                            // :206,:214
+            cursor = m_pos + m;                                            // :215
+            // table.replace(input, cursor - 2) — unconditional (:218, quirks B1/B3)
+            {
+                const uint32_t q = cursor - 2u;
+                if ((uint64_t)q + base_off > TT::kLimit) { status = LZF_CONTRACT; break; }
+                uint64_t v8 = 0;
+                if (KIND == LZF_TABLE_U32) { if (len - q >= 8u) v8 = ld8(in + q); }   // :43 else 0
+                else v8 = ld4(in + q);                                                // >= 7 bytes remain
+                const uint32_t h = TT::hash(v8);
+                if (lane == 0) tab[h] = q + boff;
+            }
+            // ================= write_group, mod.rs:150-163 (+ :235 literal slice)
+            const uint32_t lit_end = cursor - extra - 4u;
+            const uint32_t L = lit_end - ls;
+            const uint32_t nl = lsic_len(L), ne = lsic_len(extra);
+            const uint32_t total = 1u + nl + L + 2u + ne;
+            if (s.cap - s.pos < total) { status = LZF_OUTPUT_FULL; break; }
+            uint8_t* d = s.out + s.pos;
+            if (lane == 0) {
+                d[0] = (uint8_t)(((L < 15u ? L : 15u) << 4) | (extra < 15u ? extra : 15u));
+                d[1u + nl + L] = (uint8_t)dup_offset;
+                d[2u + nl + L] = (uint8_t)(dup_offset >> 8);
+            }
+            if (nl) lsic_store(d + 1, L, nl, lane);
+            wave_copy(d + 1u + nl, in + ls, L, lane);
+            if (ne) lsic_store(d + 3u + nl + L, extra, ne, lane);
+            s.pos += total;
+        }
+    }
+
+    // ---- table out (`&mut table`): mutations survive OUTPUT_FULL, like the reference's
+    if (job.table && !(job.flags & LZF_CJOB_TABLE_READONLY) && status != LZF_CONTRACT) {
+        if (KIND == LZF_TABLE_U32) {
+            lzf_u32_table* t = (lzf_u32_table*)job.table;
+            for (uint32_t i = lane; i < TT::kSlots; i += kWave) t->dict[i] = tab[i];
+        } else {
+            lzf_u16_table* t = (lzf_u16_table*)job.table;
+            for (uint32_t i = lane; i < TT::kSlots; i += kWave) t->dict[i] = (uint16_t)tab[i];
+        }
+    }
+    if (lane == 0) {
+        results[jid].out_len = s.pos;
+        results[jid].status = status;
+        results[jid].reserved = 0;
+    }
+}
+
+template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U32>(const lzf_compress_job*, lzf_job_result*, uint32_t);
+template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U16>(const lzf_compress_job*, lzf_job_result*, uint32_t);
+
+}  // namespace lzf

@@ -1,0 +1,166 @@
+"""ctypes binding of include/lzfear_hip.h (liblzfear_hip.so).
+
+Loading fails loudly if the library has not been built; calling any codec entry point fails
+loudly (LzfError) when there is no HIP device — there is no CPU fallback.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+OK, UNEXPECTED_END, MEMORY_LIMIT_EXCEEDED, ZERO_DEDUP_OFFSET, INVALID_DEDUP_OFFSET = 0, 1, 2, 3, 4
+OUTPUT_FULL, CONTRACT, OUT_CAPACITY = 5, 6, 7
+E_NO_DEVICE, E_HIP, E_INVALID = -1, -2, -3
+TABLE_U32, TABLE_U16 = 0, 1
+KINDS_U32, KINDS_U16 = 1, 2
+CJOB_TABLE_READONLY = 1
+
+
+class LzfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"lzfear_hip error {code}: {msg}")
+        self.code = code
+
+
+class U32Table(C.Structure):
+    """lzf_u32_table — src/raw/compress/mod.rs:27-36"""
+    _fields_ = [("dict", C.c_uint32 * 4096), ("offset", C.c_uint64)]
+
+
+class U16Table(C.Structure):
+    """lzf_u16_table — src/raw/compress/mod.rs:78-87"""
+    _fields_ = [("dict", C.c_uint16 * 8192), ("offset", C.c_uint64)]
+
+
+class CompressJob(C.Structure):
+    _fields_ = [("input", C.c_void_p), ("input_len", C.c_uint64), ("cursor", C.c_uint64),
+                ("out", C.c_void_p), ("out_cap", C.c_uint64), ("table", C.c_void_p),
+                ("table_kind", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class DecompressJob(C.Structure):
+    _fields_ = [("input", C.c_void_p), ("input_len", C.c_uint64), ("prefix", C.c_void_p),
+                ("prefix_len", C.c_uint64), ("out", C.c_void_p), ("out_existing_len", C.c_uint64),
+                ("out_cap", C.c_uint64), ("output_limit", C.c_uint64)]
+
+
+class JobResult(C.Structure):
+    _fields_ = [("out_len", C.c_uint64), ("status", C.c_int32), ("reserved", C.c_uint32)]
+
+
+assert C.sizeof(CompressJob) == 56 and C.sizeof(DecompressJob) == 64 and C.sizeof(JobResult) == 16
+
+EXPORTS = [
+    "lzf_abi_version", "lzf_last_error", "lzf_device_count", "lzf_compress_batch",
+    "lzf_decompress_batch", "lzf_table_seed_from_dictionary", "lzf_table_offset",
+    "lzf_xxh32_batch", "lzf_compress_batch_host", "lzf_decompress_batch_host",
+]
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def lib():
+    """Load liblzfear_hip.so (must already be built: __graft_entry__.build())."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise LzfError(E_INVALID, f"{path} is missing — run __graft_entry__.build() "
+                                      "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(path)
+        L.lzf_last_error.restype = C.c_char_p
+        L.lzf_compress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.lzf_decompress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.lzf_table_seed_from_dictionary.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+        L.lzf_table_offset.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
+        L.lzf_xxh32_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.lzf_compress_batch_host.argtypes = [C.POINTER(CompressJob), C.POINTER(JobResult), C.c_uint32]
+        L.lzf_decompress_batch_host.argtypes = [C.POINTER(DecompressJob), C.POINTER(JobResult), C.c_uint32]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc < 0:
+        raise LzfError(rc, lib().lzf_last_error().decode())
+    return rc
+
+
+def device_count():
+    return check(lib().lzf_device_count())
+
+
+# ---- host-buffer batch helpers (bytes in, bytes out) --------------------------------------
+
+def compress_blocks_host(items):
+    """items: list of dict(input=bytes, cursor=int, kind=TABLE_*, table=None|U32Table|U16Table,
+    out_cap=int, readonly=bool).  Returns list of (status, bytes)."""
+    n = len(items)
+    if n == 0:
+        return []
+    jobs = (CompressJob * n)()
+    res = (JobResult * n)()
+    keep = []
+    for i, it in enumerate(items):
+        data = bytes(it["input"])
+        cap = it.get("out_cap")
+        if cap is None:
+            cap = len(data) + len(data) // 255 + 64
+        ib = C.create_string_buffer(data, max(len(data), 1))
+        ob = C.create_string_buffer(max(cap, 1))
+        keep.append((ib, ob))
+        jobs[i].input = C.cast(ib, C.c_void_p)
+        jobs[i].input_len = len(data)
+        jobs[i].cursor = it.get("cursor", 0)
+        jobs[i].out = C.cast(ob, C.c_void_p)
+        jobs[i].out_cap = cap
+        t = it.get("table")
+        jobs[i].table = C.addressof(t) if t is not None else None
+        jobs[i].table_kind = it.get("kind", TABLE_U32)
+        jobs[i].flags = CJOB_TABLE_READONLY if it.get("readonly") else 0
+    check(lib().lzf_compress_batch_host(jobs, res, n))
+    return [(res[i].status, keep[i][1].raw[: res[i].out_len] if res[i].status == OK else b"") for i in range(n)]
+
+
+def decompress_blocks_host(items):
+    """items: list of dict(input=bytes, prefix=bytes, existing=bytes, limit=int, out_cap=int).
+    Returns list of (status, bytes incl. existing)."""
+    n = len(items)
+    if n == 0:
+        return []
+    jobs = (DecompressJob * n)()
+    res = (JobResult * n)()
+    keep = []
+    for i, it in enumerate(items):
+        data = bytes(it["input"])
+        prefix = bytes(it.get("prefix", b""))
+        existing = bytes(it.get("existing", b""))
+        limit = it.get("limit")
+        if limit is None:
+            limit = (1 << 63) - 1
+        cap = it.get("out_cap")
+        if cap is None:
+            cap = len(existing) + min(limit, 1 << 26) + len(data) + 64
+        ib = C.create_string_buffer(data, max(len(data), 1))
+        pb = C.create_string_buffer(prefix, max(len(prefix), 1))
+        ob = C.create_string_buffer(max(cap, 1))
+        ob[: len(existing)] = existing
+        keep.append((ib, pb, ob))
+        jobs[i].input = C.cast(ib, C.c_void_p)
+        jobs[i].input_len = len(data)
+        jobs[i].prefix = C.cast(pb, C.c_void_p)
+        jobs[i].prefix_len = len(prefix)
+        jobs[i].out = C.cast(ob, C.c_void_p)
+        jobs[i].out_existing_len = len(existing)
+        jobs[i].out_cap = cap
+        jobs[i].output_limit = limit
+    check(lib().lzf_decompress_batch_host(jobs, res, n))
+    out = []
+    for i in range(n):
+        ln = min(res[i].out_len, jobs[i].out_cap)
+        out.append((res[i].status, keep[i][2].raw[:ln]))
+    return out

@@ -1,0 +1,77 @@
+"""CPU tests of the drop-in boundary: the C-ABI library builds, loads, exports every symbol
+include/lzfear_hip.h declares, agrees on struct layouts, and fails loudly without a device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import rust_lz_fear_amd  # noqa: F401
+from rust_lz_fear_amd import build, ffi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build_library()
+    return ffi.lib()
+
+
+def declared_functions():
+    hdr = open(os.path.join(ROOT, "include", "lzfear_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(lzf_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_declares_expected_entry_points():
+    names = declared_functions()
+    assert "lzf_compress_batch" in names and "lzf_decompress_batch" in names
+    assert sorted(names) == sorted(ffi.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in declared_functions():
+        assert hasattr(lib, name), name
+    assert lib.lzf_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    # sizes implied by the header (LP64): compress job 56 B, decompress job 64 B, result 16 B,
+    # tables 16 KiB + 8 B
+    assert C.sizeof(ffi.CompressJob) == 56
+    assert C.sizeof(ffi.DecompressJob) == 64
+    assert C.sizeof(ffi.JobResult) == 16
+    assert C.sizeof(ffi.U32Table) == 4096 * 4 + 8 == C.sizeof(ffi.U16Table)
+    from rust_lz_fear_amd import device
+    assert device.CJOB.itemsize == 56 and device.DJOB.itemsize == 64 and device.RES.itemsize == 16
+    assert [device.CJOB.fields[n][1] for n in ("input", "input_len", "cursor", "out", "out_cap", "table", "table_kind", "flags")] == \
+        [ffi.CompressJob.input.offset, ffi.CompressJob.input_len.offset, ffi.CompressJob.cursor.offset,
+         ffi.CompressJob.out.offset, ffi.CompressJob.out_cap.offset, ffi.CompressJob.table.offset,
+         ffi.CompressJob.table_kind.offset, ffi.CompressJob.flags.offset]
+
+
+def test_no_cpu_fallback(lib):
+    """Without a HIP device every codec entry point must fail loudly — never compute on the CPU."""
+    n = lib.lzf_device_count()
+    if n > 0:
+        pytest.skip("a GPU is present; the loud-failure path is for GPU-less hosts")
+    assert n == ffi.E_NO_DEVICE
+    with pytest.raises(ffi.LzfError):
+        ffi.compress_blocks_host([dict(input=b"hello hello hello hello")])
+    with pytest.raises(ffi.LzfError):
+        ffi.decompress_blocks_host([dict(input=bytes([0x11, 97, 1, 0]))])
+    assert b"no CPU fallback" in lib.lzf_last_error()
+
+
+def test_product_does_not_reference_oracle():
+    """The oracle is test infrastructure: nothing under the package or include/ may mention it."""
+    bad = []
+    for base in ("rust-lz-fear_amd", "include"):
+        for dp, _, fns in os.walk(os.path.join(ROOT, base)):
+            for fn in fns:
+                if fn.endswith((".py", ".hip", ".h", ".cpp", ".hpp")):
+                    txt = open(os.path.join(dp, fn), errors="ignore").read()
+                    if re.search(r"oracle_ffi|lzf_oracle|liblzf_oracle|lzfo_", txt):
+                        bad.append(os.path.join(dp, fn))
+    assert not bad, bad

@@ -1,0 +1,336 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on
+the same seeded inputs — bit-exact for compress2 output bytes, decoded bytes and error kinds."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as o
+import vectors
+import rust_lz_fear_amd  # noqa: F401
+from rust_lz_fear_amd import ffi, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def gpu_compress(items):
+    return ffi.compress_blocks_host(items)
+
+
+def gpu_decompress(items):
+    return ffi.decompress_blocks_host(items)
+
+
+def test_device_present():
+    assert ffi.device_count() >= 1
+
+
+# ---------------------------------------------------------------- decompress
+def test_decode_kats():
+    res = gpu_decompress([dict(input=d) for d, _, _ in vectors.DECODE_KATS])
+    for (d, status, expect), (rc, out) in zip(vectors.DECODE_KATS, res):
+        assert rc == status, d
+        if expect is not None:
+            assert out == expect
+
+
+def all_cases():
+    return vectors.small_cases() + vectors.medium_cases() + [(f"librs{i}", s) for i, s in enumerate(vectors.LIB_RS_STRINGS)]
+
+
+def test_decompress_valid_blocks_matches_original():
+    cases = all_cases()
+    comps = [o.compress2(d)[1] for _, d in cases]
+    res = gpu_decompress([dict(input=c, limit=max(len(d), 1), out_cap=len(d) + len(c) + 64) for c, (_, d) in zip(comps, cases)])
+    for (name, d), (rc, out) in zip(cases, res):
+        assert rc == 0, name
+        assert out == d, name
+
+
+def test_decompress_u16_streams_and_c_streams():
+    cases = [(n, d) for n, d in all_cases() if 0 < len(d) <= 0xFFFF]
+    comps = [o.compress2(d, kind=o.TABLE_U16)[1] for _, d in cases]
+    res = gpu_decompress([dict(input=c, limit=len(d)) for c, (_, d) in zip(comps, cases)])
+    for (name, d), (rc, out) in zip(cases, res):
+        assert (rc, out) == (0, d), name
+
+
+def mutate(rng, comp):
+    b = bytearray(comp)
+    kind = rng.integers(0, 5)
+    if kind == 0 and len(b) > 1:           # truncate
+        del b[rng.integers(1, len(b)):]
+    elif kind == 1 and len(b) > 0:         # flip a byte
+        i = rng.integers(0, len(b)); b[i] ^= 1 << rng.integers(0, 8)
+    elif kind == 2 and len(b) > 0:         # set a byte to 0 / 0xFF (zero offsets, LSIC runs)
+        i = rng.integers(0, len(b)); b[i] = 0 if rng.integers(0, 2) else 0xFF
+    elif kind == 3:                        # append garbage
+        b += bytes(rng.integers(0, 256, rng.integers(1, 9), dtype=np.uint8))
+    else:                                  # several flips
+        for _ in range(4):
+            if len(b):
+                i = rng.integers(0, len(b)); b[i] = rng.integers(0, 256)
+    return bytes(b)
+
+
+def test_decompress_malformed_inputs_same_error_kind():
+    """The decode corpus idea (fuzz/fuzz_targets/decode.rs) at block level: mutated blocks must
+    give the same DecodeError kind as the reference restatement, and the same bytes when Ok."""
+    rng = np.random.default_rng(12345)
+    base = [(n, d) for n, d in all_cases() if 0 < len(d) <= 300000]
+    items, expect = [], []
+    for name, d in base:
+        comp = o.compress2(d)[1]
+        for k in range(6):
+            m = mutate(rng, comp)
+            limit = len(d) if k % 2 == 0 else len(d) // 2 + 1
+            cap = limit + len(m) + 64
+            erc, eout = o.decompress_raw(m, limit=limit, cap=cap)
+            items.append(dict(input=m, limit=limit, out_cap=cap))
+            expect.append((name, k, erc, eout))
+    res = gpu_decompress(items)
+    kinds = set()
+    for (name, k, erc, eout), (rc, out) in zip(expect, res):
+        assert rc == erc, (name, k, rc, erc)
+        kinds.add(rc)
+        if rc == 0:
+            assert out == eout, (name, k)
+    assert {0, 1, 2, 3, 4} <= kinds      # every DecodeError variant was exercised
+
+
+def test_decompress_prefix_and_existing_output():
+    d = synth.gen_text_zipf(31, 50000).tobytes()
+    dic, payload = d[:20000], d[20000:]
+    # compress payload with the dictionary as addressable prefix
+    rc, comp = o.compress2(dic + payload, cursor=len(dic))
+    assert rc == 0
+    items = [
+        dict(input=comp, prefix=dic, limit=len(payload)),                       # dictionary as prefix
+        dict(input=comp, existing=dic, limit=len(d)),                           # dictionary as existing output
+        dict(input=comp, prefix=dic[:100], limit=len(payload)),                 # truncated dictionary
+        dict(input=comp, prefix=dic[:10000], existing=dic[10000:], limit=len(d)),  # split
+    ]
+    res = gpu_decompress(items)
+    exp = [o.decompress_raw(comp, prefix=it.get("prefix", b""), existing=it.get("existing", b""), limit=it["limit"]) for it in items]
+    for (rc, out), (erc, eout) in zip(res, exp):
+        assert rc == erc
+        if rc == 0:
+            assert out == eout
+    assert res[0] == (0, payload) and res[1] == (0, d) and res[3] == (0, d)
+    assert res[2][0] == o.INVALID_DEDUP_OFFSET
+
+
+def test_decompress_overlap_offsets():
+    """copy_overlapping arms (decompress.rs:100-135): offsets 1..40 with long matches."""
+    items, exp = [], []
+    for off in list(range(1, 41)) + [63, 64, 65, 255, 256, 257, 1000]:
+        for mlen in (4, 5, 19, 70, 300, 5000):
+            lit = bytes((i * 7 + off) & 0xFF for i in range(off))
+            tok_l = min(len(lit), 15); tok_m = min(mlen - 4, 15)
+            blk = bytes([(tok_l << 4) | tok_m])
+            if len(lit) >= 15:
+                v = len(lit) - 15
+                blk += b"\xff" * (v // 255) + bytes([v % 255])
+            blk += lit + off.to_bytes(2, "little")
+            if mlen - 4 >= 15:
+                v = mlen - 4 - 15
+                blk += b"\xff" * (v // 255) + bytes([v % 255])
+            items.append(dict(input=blk))
+            exp.append(o.decompress_raw(blk))
+    res = gpu_decompress(items)
+    for e, r in zip(exp, res):
+        assert e[0] == 0 and r == e
+
+
+# ---------------------------------------------------------------- compress
+def test_compress_u32_bit_exact():
+    cases = all_cases()
+    res = gpu_compress([dict(input=d) for _, d in cases])
+    for (name, d), (rc, comp) in zip(cases, res):
+        erc, ecomp = o.compress2(d)
+        assert rc == erc == 0, name
+        assert comp == ecomp, (name, len(comp), len(ecomp))
+
+
+def test_compress_u16_bit_exact():
+    cases = [(n, d) for n, d in all_cases() if len(d) <= 0xFFFF]
+    res = gpu_compress([dict(input=d, kind=ffi.TABLE_U16) for _, d in cases])
+    for (name, d), (rc, comp) in zip(cases, res):
+        erc, ecomp = o.compress2(d, kind=o.TABLE_U16)
+        assert rc == erc == 0, name
+        assert comp == ecomp, name
+    rc, _ = gpu_compress([dict(input=bytes(65536), kind=ffi.TABLE_U16)])[0]
+    assert rc == ffi.CONTRACT                                     # mod.rs:167
+
+
+def test_compress_survey_fingerprints():
+    S = json.load(open(os.path.join(GOLD, "survey_fingerprints.json")))
+    e = bytearray(synth.lcg_bytes(1, 156)); e[143:149] = e[11:17]
+    g1 = vectors.big_compression_bytes(10 ** 6)
+    g3 = synth.lcg_bytes(5, 262144, 3)
+    g4 = synth.lcg_bytes(7, 65535, 1)
+    res = gpu_compress([dict(input=bytes(e)), dict(input=g1), dict(input=bytes(65536)), dict(input=g3),
+                        dict(input=g4, kind=ffi.TABLE_U16), dict(input=g4)])
+    fp = lambda b: [len(b), "%08x" % o.xxh32(b)]
+    assert [rc for rc, _ in res] == [0] * 6
+    assert fp(res[0][1]) == S["KAT-A"]["u32_raw"]                  # quirk B2
+    assert fp(res[1][1]) == S["G1"]["u32_raw"]
+    assert fp(res[2][1]) == S["G2"]["u32_raw"]
+    assert fp(res[3][1]) == S["G3"]["u32_raw"]
+    assert fp(res[4][1]) == S["G4"]["u16_raw"]
+    assert fp(res[5][1]) == S["G4"]["u32_raw"]
+
+
+def test_compress_output_full_cap():
+    """NoPartialWrites cap = N (framed/compress.rs:242): incompressible blocks abort, C == N passes."""
+    d = vectors.rng_bytes(11, 5000)
+    rc, full = o.compress2(d)
+    res = gpu_compress([dict(input=d, out_cap=len(d)), dict(input=d, out_cap=len(full)), dict(input=d, out_cap=len(full) - 1),
+                        dict(input=d, out_cap=0), dict(input=b"", out_cap=0)])
+    assert res[0][0] == ffi.OUTPUT_FULL
+    assert res[1] == (0, full)
+    assert res[2][0] == ffi.OUTPUT_FULL
+    assert res[3][0] == ffi.OUTPUT_FULL
+    assert res[4] == (0, b"")                                      # quirk B4
+
+
+def test_compress_with_prefix_and_table_carry_linked_blocks():
+    """cursor > 0 + carried table == the linked-blocks driver of framed/compress.rs:221-276."""
+    data = synth.silesia_mix(20 << 20, (20 << 20) + 300000).tobytes()
+    bs = 65536
+    tg, to = ffi.U32Table(), o.new_table()
+    buf = b""
+    for off in range(0, len(data), bs):
+        blk = data[off:off + bs]
+        inp = buf + blk
+        erc, ecomp = o.compress2(inp, cursor=len(buf), table=to, cap=len(blk))
+        (rc, comp), = gpu_compress([dict(input=inp, cursor=len(buf), table=tg, out_cap=len(blk))])
+        assert rc == erc, off
+        if rc == 0:
+            assert comp == ecomp, off
+        assert bytes(tg) == bytes(to), off        # table state after the block is identical
+        buf = inp
+        if len(buf) > 65536:
+            forget = len(buf) - 65536
+            tg.offset += forget; to.offset += forget
+            buf = buf[forget:]
+
+
+def test_compress_dictionary_template_table():
+    """Template table seeded from a dictionary (framed/compress.rs:202-214), read-only clone per block."""
+    dic = synth.gen_text_zipf(3, 70000).tobytes()
+    blocks = [synth.gen_text_zipf(40 + i, 65536).tobytes() for i in range(4)]
+    # oracle: seed by the reference loop
+    tmpl = o.new_table()
+    import ctypes as C
+    contract = C.c_int(0)
+    rep = o.lib().lzfo_u32_replace
+    rep.restype = C.c_size_t
+    rep.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int)]
+    for off in range(0, len(dic) - 7, 3):
+        rep(C.addressof(tmpl), dic, len(dic), off, C.byref(contract))
+    items, exp = [], []
+    for b in blocks:
+        t = o.U32Table.from_buffer_copy(bytes(tmpl))
+        exp.append(o.compress2(dic + b, cursor=len(dic), table=t, cap=len(b)))
+        tg = ffi.U32Table.from_buffer_copy(bytes(tmpl))
+        items.append(dict(input=dic + b, cursor=len(dic), table=tg, out_cap=len(b), readonly=True))
+    res = gpu_compress(items)
+    for e, r, it in zip(exp, res, items):
+        assert r == e
+        assert bytes(it["table"]) == bytes(tmpl)      # readonly: template untouched
+
+
+def test_device_table_seeding_matches_reference_loop():
+    import ctypes as C
+    import torch
+    dic = synth.gen_text_zipf(3, 70000).tobytes()
+    tmpl = o.new_table()
+    contract = C.c_int(0)
+    rep = o.lib().lzfo_u32_replace
+    rep.restype = C.c_size_t
+    rep.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int)]
+    for off in range(0, len(dic) - 7, 3):
+        rep(C.addressof(tmpl), dic, len(dic), off, C.byref(contract))
+    d_dic = torch.frombuffer(bytearray(dic), dtype=torch.uint8).cuda()
+    d_tab = torch.zeros(C.sizeof(ffi.U32Table), dtype=torch.uint8, device="cuda")
+    ffi.check(ffi.lib().lzf_table_seed_from_dictionary(d_tab.data_ptr(), d_dic.data_ptr(), len(dic), None))
+    torch.cuda.synchronize()
+    assert d_tab.cpu().numpy().tobytes() == bytes(tmpl)
+    for short in (0, 4, 7, 8, 9, 11):
+        ffi.check(ffi.lib().lzf_table_seed_from_dictionary(d_tab.data_ptr(), d_dic.data_ptr(), short, None))
+        t2 = o.new_table()
+        for off in range(0, short - 7, 3):
+            rep(C.addressof(t2), dic[:short], short, off, C.byref(contract))
+        torch.cuda.synchronize()
+        assert d_tab.cpu().numpy().tobytes() == bytes(t2), short
+
+
+def test_xxh32_batch():
+    import torch
+    bufs = [vectors.rng_bytes(i, n) for i, n in enumerate([0, 1, 3, 4, 15, 16, 17, 31, 32, 33, 63, 64, 100, 1000, 65536, 300001] * 2 + [5] * 7)]
+    blob = b"".join(bufs)
+    d = torch.frombuffer(bytearray(blob + b"\0"), dtype=torch.uint8).cuda()
+    offs = np.cumsum([0] + [len(b) for b in bufs[:-1]]).astype(np.uint64)
+    ptrs = torch.from_numpy((offs + np.uint64(d.data_ptr())).view(np.int64)).cuda()
+    lens = torch.from_numpy(np.array([len(b) for b in bufs], dtype=np.int64)).cuda()
+    out = torch.zeros(len(bufs), dtype=torch.int32, device="cuda")
+    ffi.check(ffi.lib().lzf_xxh32_batch(ptrs.data_ptr(), lens.data_ptr(), out.data_ptr(), len(bufs), None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint32)
+    for g, b in zip(got, bufs):
+        assert int(g) == o.xxh32(b)
+
+
+# ---------------------------------------------------------------- BASELINE sizes (4 MiB blocks)
+def test_full_size_silesia_blocks_bit_exact_and_roundtrip():
+    """configs[1]/[2]: every 4 MiB block of the 211 938 580-byte Silesia stand-in (51 blocks):
+    GPU compress == oracle compress byte-for-byte (or both abort to 'stored'), GPU decompress of
+    those bytes == the input.  Device-resident path (lzf_*_batch with HBM job arrays)."""
+    import torch
+    from rust_lz_fear_amd import device
+    data = synth.silesia_mix()
+    bs = 4 << 20
+    d_in = torch.from_numpy(data).cuda()
+    blocks = device.BlockSet(d_in, bs)
+    assert blocks.n == 51
+    d_out = torch.empty(blocks.n * bs, dtype=torch.uint8, device="cuda")
+    jobs = blocks.compress_jobs(d_out, bs)
+    d_jobs = device.to_device(jobs, "cuda")
+    d_res = torch.zeros(blocks.n * 16, dtype=torch.uint8, device="cuda")
+    device.compress_batch(d_jobs, d_res, blocks.n)
+    torch.cuda.synchronize()
+    res = device.results_to_host(d_res, blocks.n)
+    comp_host = d_out.cpu().numpy()
+    stored = 0
+    dj = np.zeros(blocks.n, dtype=device.DJOB)
+    d_dec = torch.zeros(blocks.n * bs, dtype=torch.uint8, device="cuda")
+    for i in range(blocks.n):
+        blk = data[i * bs:(i + 1) * bs].tobytes()
+        erc, ecomp = o.compress2(blk, cap=len(blk))
+        assert int(res["status"][i]) == erc, i
+        if erc == 0:
+            assert int(res["out_len"][i]) == len(ecomp), i
+            assert comp_host[i * bs:i * bs + len(ecomp)].tobytes() == ecomp, i
+        else:
+            stored += 1
+        dj["input"][i] = d_out.data_ptr() + i * bs
+        dj["input_len"][i] = res["out_len"][i] if erc == 0 else 0
+        dj["out"][i] = d_dec.data_ptr() + i * bs
+        dj["out_cap"][i] = bs
+        dj["output_limit"][i] = bs
+    assert 0 < stored < 10          # the near-random segments (sao, x-ray) are stored raw
+    d_dj = device.to_device(dj, "cuda")
+    d_res2 = torch.zeros(blocks.n * 16, dtype=torch.uint8, device="cuda")
+    device.decompress_batch(d_dj, d_res2, blocks.n)
+    torch.cuda.synchronize()
+    res2 = device.results_to_host(d_res2, blocks.n)
+    dec = d_dec.cpu().numpy()
+    for i in range(blocks.n):
+        assert int(res2["status"][i]) == 0
+        if int(res["status"][i]) == 0:
+            n = int(blocks.lens[i])
+            assert int(res2["out_len"][i]) == n
+            assert np.array_equal(dec[i * bs:i * bs + n], data[i * bs:i * bs + n]), i

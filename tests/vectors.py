@@ -1,0 +1,69 @@
+"""Shared seeded test inputs (CPU-side; used by oracle tests and by the GPU parity tests)."""
+import numpy as np
+
+import rust_lz_fear_amd  # noqa: F401  (import shim)
+from rust_lz_fear_amd import synth
+
+# The round-trip strings of the reference's unit tests (src/lib.rs:43-95) — test *data*.
+LIB_RS_STRINGS = [
+    b"to live or not to live",
+    b"Love is a wonderful terrible thing",
+    b"There is nothing either good or bad, but thinking makes it so.",
+    b"I burn, I pine, I perish.",
+    b"To cute to die! Save the red panda!",
+    b"You are 60% water. Save 60% of yourself!",
+    b"Save water, it doesn't grow on trees.",
+    b"The panda bear has an amazing black-and-white fur.",
+    b"The average panda eats as much as 9 to 14 kg of bamboo shoots a day.",
+    b"The Empress Dowager Bo was buried with a panda skull in her vault",
+    b"as6yhol.;jrew5tyuikbfewedfyjltre22459ba",
+    b"jhflkdjshaf9p8u89ybkvjsdbfkhvg4ut08yfrr",
+    b"ahhd", b"ahd", b"x-29", b"x", b"k", b".", b"ajsdh", b"",
+    b"\0" * 13,
+    b"The Read trait allows for reading bytes from a source. Implementors of the Read trait are "
+    b"called 'readers'. Readers are defined by one required method, read().",
+]
+
+# decode KATs of src/raw/decompress.rs:153-175: (input, expected status name, expected output)
+DECODE_KATS = [
+    (bytes([0x11, ord("a"), 1, 0]), 0, b"aaaaaa"),
+    (bytes([0x11, ord("a"), 1, 0, 0x22, ord("b"), ord("c"), 2, 0]), 0, b"aaaaaabcbcbcbc"),
+    (bytes([0x30, ord("a"), ord("4"), ord("9")]), 0, b"a49"),
+    (bytes([0x10, ord("a"), 2, 0]), 4, None),   # offset_oob -> InvalidDeduplicationOffset
+    (bytes([0x40, ord("a"), 1, 0]), 1, None),   # literal run past the end -> UnexpectedEnd
+]
+
+
+def big_compression_bytes(n):
+    """src/lib.rs:98-106 generator: (n as u8)*10 + 33 ^ 0xA2."""
+    k = np.arange(n, dtype=np.uint64)
+    return (((k & 0xFF) * 10 + 33) & 0xFF ^ 0xA2).astype(np.uint8).tobytes()
+
+
+def rng_bytes(seed, n):
+    return synth.gen_random(seed, n).tobytes()
+
+
+def small_cases():
+    """Adversarially small / boundary inputs (the 12-byte MFLIMIT and 5-byte LASTLITERALS rules)."""
+    cases = []
+    for n in list(range(0, 40)) + [63, 64, 65, 66, 67, 127, 128, 129, 255, 256, 257, 300, 1000]:
+        cases.append((f"zeros{n}", bytes(n)))
+        cases.append((f"ab{n}", (b"ab" * n)[:n]))
+        cases.append((f"rnd{n}", rng_bytes(1000 + n, n)))
+        cases.append((f"text{n}", synth.gen_text_zipf(77, max(n, 1)).tobytes()[:n]))
+    return cases
+
+
+def medium_cases():
+    cases = []
+    for i, (name, _, cls, kw) in enumerate(synth.SILESIA_SEGMENTS):
+        cases.append((f"{name}_256k", synth.CLASSES[cls](4242 + i, 256 << 10, **kw).tobytes()))
+    cases.append(("log_512k", synth.gen_log(5, 512 << 10).tobytes()))
+    cases.append(("repeat256_64k", synth.repeat256(65536).tobytes()))
+    cases.append(("zeros_1m", bytes(1 << 20)))
+    cases.append(("bench_shape_1m", bytes(200000) + rng_bytes(9, 400000) + bytes(400000)))  # benches/my_benchmark.rs:12-13 shape
+    cases.append(("bigcomp_1m", big_compression_bytes(1 << 20)))
+    cases.append(("lcg3_mask3_69632", synth.lcg_bytes(3, 69632, 3)))
+    cases.append(("mixed_1m", synth.silesia_mix(9 << 20, 10 << 20).tobytes()))
+    return cases
