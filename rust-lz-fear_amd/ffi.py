@@ -67,6 +67,12 @@ def lib():
     """Load liblzfear_hip.so (must already be built: __graft_entry__.build())."""
     global _lib
     if _lib is None:
+        try:
+            # One HIP runtime per process: when torch is installed, load its ROCm libraries
+            # first so that liblzfear_hip.so binds to the same libamdhip64 torch uses.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         path = lib_path()
         if not os.path.exists(path):
             raise LzfError(E_INVALID, f"{path} is missing — run __graft_entry__.build() "

@@ -118,7 +118,7 @@ def test_decompress_prefix_and_existing_output():
         assert rc == erc
         if rc == 0:
             assert out == eout
-    assert res[0] == (0, payload) and res[1] == (0, d) and res[3] == (0, d)
+    assert res[0] == (0, payload) and res[1] == (0, d) and res[3] == (0, dic[10000:] + payload)
     assert res[2][0] == o.INVALID_DEDUP_OFFSET
 
 
