@@ -105,7 +105,7 @@ typedef struct lzf_decompress_job {
 typedef struct lzf_job_result {
     uint64_t out_len;             /* compress: bytes written; decompress: output.len() (incl. existing) */
     int32_t status;               /* LZF_OK ... LZF_OUT_CAPACITY; out_len is unspecified on error */
-    uint32_t reserved;
+    uint32_t reserved;            /* diagnostic only: kilo-cycles the job's wavefront ran */
 } lzf_job_result;
 
 /* ---- library ---------------------------------------------------------------------------- */

@@ -6,9 +6,9 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.path.join(PKG_DIR, "liblzfear_hip.so")
+LIB_PATH = os.environ.get("LZF_LIB_PATH") or os.path.join(PKG_DIR, "liblzfear_hip.so")   # override: debug builds only
 
-HIP_SOURCES = ["capi.hip", "lz4_decompress.hip", "lz4_compress.hip", "aux_kernels.hip"]
+HIP_SOURCES = ["capi.hip", "lz4_decompress.hip", "lz4_decompress_batched.hip", "lz4_compress.hip", "aux_kernels.hip"]
 CXX_SOURCES = []
 DEPS = HIP_SOURCES + CXX_SOURCES + ["kernels.h", "lzf_device.h", os.path.join(ROOT, "include", "lzfear_hip.h")]
 
@@ -31,14 +31,15 @@ def hipcc():
     return "hipcc"
 
 
-def build_library(force=False, verbose=False):
+def build_library(force=False, verbose=False, defines=(), out=None):
     """hipcc --offload-arch=gfx950 -> rust-lz-fear_amd/liblzfear_hip.so"""
-    if not force and not _stale():
-        return LIB_PATH
+    out = out or LIB_PATH
+    if not force and not defines and not _stale():
+        return out
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH]
+           "-I", os.path.join(ROOT, "include"), "-o", out] + [f"-D{d}" for d in defines]
     cmd += [os.path.join(CSRC, s) for s in HIP_SOURCES + CXX_SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return out

@@ -3,6 +3,7 @@
 // usable HIP device every entry point fails with LZF_E_NO_DEVICE.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -33,6 +34,20 @@ int ensure_device() {
         return LZF_E_NO_DEVICE;
     }
     return n;
+}
+
+// Kernel generation used by lzf_decompress_batch.  Tuning / A-B knob only (both generations
+// implement the same contract): LZF_DECOMPRESS_KERNEL = wave | batched8 | batched16 | batched32.
+int decompress_variant() {
+    static const int v = [] {
+        const char* e = getenv("LZF_DECOMPRESS_KERNEL");
+        if (!e || !*e) return 16;
+        if (!strcmp(e, "wave")) return 0;
+        if (!strcmp(e, "batched8")) return 8;
+        if (!strcmp(e, "batched32")) return 32;
+        return 16;
+    }();
+    return v;
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -75,7 +90,12 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
     int rc = ensure_device();
     if (rc < 0) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    hipLaunchKernelGGL(lzf::lzf_decompress_wave_kernel, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs);
+    switch (decompress_variant()) {
+        case 0: hipLaunchKernelGGL(lzf::lzf_decompress_wave_kernel, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
+        case 8: hipLaunchKernelGGL(lzf::lzf_decompress_batched_kernel<8192>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
+        case 32: hipLaunchKernelGGL(lzf::lzf_decompress_batched_kernel<32768>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
+        default: hipLaunchKernelGGL(lzf::lzf_decompress_batched_kernel<16384>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
+    }
     HIP_TRY(hipGetLastError());
     return LZF_OK;
 }

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
     if (jid >= n_jobs) return;
     const uint32_t lane = threadIdx.x;
     const lzf_compress_job job = jobs[jid];
+    const long long t_start = clock64();
     if (job.table_kind != (uint32_t)KIND) return;   // handled by the other instantiation
 
     const uint8_t* __restrict__ in = job.input;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
     if (lane == 0) {
         results[jid].out_len = s.pos;
         results[jid].status = status;
-        results[jid].reserved = 0;
+        results[jid].reserved = (uint32_t)((clock64() - t_start) >> 10);   // diagnostic: shader kilo-cycles spent on this job
     }
 }
 

@@ -59,6 +59,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_wave_kernel(
     if (jid >= n_jobs) return;
     const uint32_t lane = threadIdx.x;
     const lzf_decompress_job job = jobs[jid];
+    const long long t_start = clock64();
 
     int status = LZF_OK;
     uint32_t o = 0;
@@ -152,7 +153,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_wave_kernel(
     if (lane == 0) {
         results[jid].out_len = o;
         results[jid].status = status;
-        results[jid].reserved = 0;
+        results[jid].reserved = (uint32_t)((clock64() - t_start) >> 10);   // diagnostic: shader kilo-cycles spent on this job
     }
 }
 
