@@ -1,24 +1,31 @@
 // lz4_decompress_batched.hip — batched raw::decompress_raw for gfx950, second generation.
 //
-// Same contract as lz4_decompress.hip (src/raw/decompress.rs:58-138, one wavefront per block),
-// but the per-sequence memory round trips of the first kernel are gone:
+// Same contract as lz4_decompress.hip (src/raw/decompress.rs:58-138, one wavefront per block).
+// The sequential token walk of LZ4 decoding is the part a GPU does worst (one dependent,
+// data-dependent hop per sequence), so this kernel splits decoding into two stages per chunk
+// of compressed input:
 //
-//   * the wave parses up to 64 sequences ahead (wave-uniform scalar walk over a 256-byte
-//     register window of the compressed input) and gives sequence j to lane j;
-//   * the most recent RING bytes of output live in an LDS ring (ring index == output address
-//     mod RING, so 16-byte chunks of the ring line up with 16-byte chunks of HBM).  All of a
-//     batch's output is assembled in the ring: literals (lane-parallel, register staged),
-//     "far" matches (source older than the ring's intact history: read back from HBM with two
-//     16-byte loads per lane) and "near" matches (ring -> ring);
-//   * near matches are resolved in rounds against a high-water mark H = start of the first
-//     unresolved match: a lane may copy once its whole source lies below H.  Overlapping
-//     matches use the period-`offset` form dst[t] = src[t mod offset], so all their reads
-//     precede the match as well.  LDS executes a wave's accesses in order, so no barrier or
-//     wait separates the rounds;
-//   * the finished batch is flushed ring -> HBM with aligned 16-byte stores (coalesced
-//     write stream, every output byte written once).
-//   * a sequence too large for a batch (> RING/4 bytes) takes a solo path: cooperative
-//     HBM -> HBM copies as in the first kernel, then the ring is re-filled from HBM.
+//   PARSE (lane-parallel, speculative).  A chunk is 64 regions of S bytes, one per lane.  Every
+//   lane walks the token chain of its region at once, starting from a guess (the region start).
+//   A walk from a wrong position re-synchronises with the true chain after a few hops, and the
+//   exit of a region (first token at or beyond its end) is the true start of the next one, so
+//   the wave iterates  start[i] <- max(exit[0..i-1])  until nothing changes; lane 0 starts from a
+//   known-true token, hence the fixed point is the true chain (lane i is exact after i+1
+//   passes at worst; typical data needs 3-4).  A final pass records the token positions,
+//   compacted in stream order, into an LDS list.
+//
+//   COPY (lane-parallel, batched).  64 consecutive sequences go to the 64 lanes.  The most
+//   recent RING bytes of output live in an LDS ring (ring index == output address mod RING, so
+//   16-byte chunks of the ring line up with 16-byte chunks of HBM).  Literals are staged
+//   through registers into the ring; "far" matches (older than the ring's intact history) are
+//   read back from HBM with two 16-byte loads per lane; "near" matches copy ring -> ring — all
+//   lanes at once when their source lies below the first unresolved match, the remainder
+//   strictly in stream order.  Overlapping matches use dst[t] = src[t mod offset], whose reads
+//   all precede the match.  LDS executes one wave's accesses in order, so no barrier or wait
+//   separates dependent copies.  The finished batch is flushed ring -> HBM with aligned
+//   16-byte stores: every output byte is written to HBM exactly once, coalesced.
+//   A sequence too large for a batch (> RING/4 output bytes) takes a solo path (cooperative
+//   HBM -> HBM copies, then the ring is re-filled from HBM).
 //
 // Error precedence is the reference's: within a sequence literal EOF / LSIC EOF
 // (UnexpectedEnd), MemoryLimitExceeded, ZeroDeduplicationOffset, InvalidDeduplicationOffset
@@ -31,34 +38,16 @@ namespace {
 
 constexpr uint32_t kMaxPosB = 0x7FFFFF00u;
 constexpr uint32_t kShort = 32;          // bytes a lane moves by itself; longer runs are cooperative
-
-struct InWindowB {
-    const uint8_t* in;
-    uint32_t len;
-    uint32_t base;
-    uint32_t w, wn;
-    __device__ __forceinline__ uint32_t fetch(uint32_t b, uint32_t lane) const {
-        const uint32_t a = b + lane * 4u;
-        uint32_t v = 0;
-        if (a + 4u <= len) v = ld4(in + a);
-        else if (a < len) { for (uint32_t i = 0; a + i < len; ++i) v |= (uint32_t)in[a + i] << (8u * i); }
-        return v;
-    }
-    __device__ __forceinline__ uint32_t byte(uint32_t p, uint32_t lane) {
-        const uint32_t b = p & ~255u;
-        if (b != base) {
-            if (b == base + 256u) w = wn; else w = fetch(b, lane);
-            base = b;
-            if (b + 256u < len) wn = fetch(b + 256u, lane);
-        }
-        const uint32_t d = __builtin_amdgcn_readlane(w, (p >> 2) & 63u);
-        return (d >> ((p & 3u) * 8u)) & 0xFFu;
-    }
-};
+constexpr uint32_t kTotClamp = 1u << 25; // per-sequence output clamp inside the position scan
 
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = __shfl_xor(v, m); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t t = __shfl_up(v, d); if (lane >= d) v += t; }
     return v;
 }
 
@@ -70,15 +59,46 @@ __device__ __forceinline__ uint32_t safe_ld4(const uint8_t* in, uint32_t len, ui
     return v;
 }
 
+// One token of the stream at p (p < len): position of the next token, or an error.
+// decompress.rs:61-71 without the copies.  Returns false on UnexpectedEnd.
+__device__ __forceinline__ bool token_next(const uint8_t* __restrict__ in, uint32_t len, uint32_t p, uint32_t& next) {
+    const uint32_t tok = in[p];
+    uint32_t q = p + 1u;
+    uint32_t L = tok >> 4;
+    if (L == 15u) {
+        for (;;) {
+            if (q >= len) return false;
+            const uint32_t b = in[q++];
+            L += b; if (L > kMaxPosB) L = kMaxPosB;
+            if (b != 255u) break;
+        }
+    }
+    if (len - q < L) return false;                    // :67 read_exact
+    q += L;
+    if (len - q < 2u) { next = len; return true; }    // :70 read_u16 fails: last literals
+    q += 2u;
+    if ((tok & 15u) == 15u) {
+        for (;;) {
+            if (q >= len) return false;
+            const uint32_t b = in[q++];
+            if (b != 255u) break;
+        }
+    }
+    next = q;
+    return true;
+}
+
 }  // namespace
 
-template <int RING>
+template <int RING, int S, int TOKCAP>
 __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
     const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs) {
     constexpr uint32_t kMask = RING - 1;
     constexpr uint32_t kSpanMax = RING / 4;            // output bytes one batch may produce
     constexpr uint32_t kNearHist = RING - kSpanMax;    // history before the batch that stays intact in the ring
+    static_assert(S * 64 <= 65536, "token positions are stored as u16 offsets into the chunk");
     __shared__ __attribute__((aligned(16))) uint8_t ring[RING];
+    __shared__ uint16_t toks[TOKCAP];
 
     const uint32_t jid = blockIdx.x;
     if (jid >= n_jobs) return;
@@ -130,8 +150,6 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
         o = (uint32_t)job.out_existing_len;
         uint32_t safe = o;   // out[0, safe) is visible to this wave's global loads
         if (o > 0) ring_fill(o > (uint32_t)RING ? o - RING : 0u, o);   // Vec content on entry = history
-        uint32_t p = 0;
-        InWindowB win{in, len, 0xFFFFFFFFu, 0u, 0u};
 
 #ifdef LZF_PHASE_TIMING
         long long tph[6] = {0, 0, 0, 0, 0, 0}; long long tq = clock64();
@@ -139,98 +157,176 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
 #else
 #define PHASE(i) do { } while (0)
 #endif
-        while (p < len && status == LZF_OK) {
+        uint32_t cstart = 0;                 // a true token position (or len)
+        while (cstart < len && status == LZF_OK) {
             // =====================================================================
-            // A. parse up to 64 sequences (decompress.rs:61-74), wave-uniform
+            // A. speculative lane-parallel parse of one chunk: regions [cstart + i*S, +S)
             // =====================================================================
-            const uint32_t ob0 = o;
-            uint32_t nseq = 0, o_run = o, maxL = 0;
-            uint32_t v_src = 0, v_L = 0, v_M = 0, v_lo = 0, v_fl = 0;   // lane j = sequence j
-            int perr = LZF_OK;
-            bool solo = false;
-            uint32_t s_src = 0, s_L = 0, s_M = 0; bool s_has = false; uint32_t s_offpos = 0;
-
-            while (nseq < kWave && p < len) {
-                const uint32_t tp = p;
-                const uint32_t token = win.byte(p, lane); ++p;
-                uint32_t L = token >> 4;
-                if (L == 15u) {
-                    bool eof = false;
-                    for (;;) {
-                        if (p >= len) { eof = true; break; }
-                        const uint32_t b = win.byte(p, lane); ++p;
-                        L += b; if (L > kMaxPosB) L = kMaxPosB;
-                        if (b != 255u) break;
-                    }
-                    if (eof) { perr = LZF_UNEXPECTED_END; break; }
+            const uint32_t rbeg = cstart + lane * (uint32_t)S;
+            const uint32_t rend = rbeg + (uint32_t)S;
+            uint32_t start = lane == 0 ? cstart : (rbeg < len ? rbeg : len);
+            uint32_t x = 0, n = 0;
+            bool lerr = false;
+            for (uint32_t pass = 0; pass < 70u; ++pass) {
+                uint32_t p = start;
+                n = 0; lerr = false;
+                while (p < rend && p < len) {
+                    uint32_t nx;
+                    if (!token_next(in, len, p, nx)) { lerr = true; p = len; break; }
+                    ++n; p = nx;
                 }
-                if (len - p < L) { perr = LZF_UNEXPECTED_END; break; }            // :67
-                const uint32_t src = p;
-                uint32_t q = p + L, M = 0; bool has = true;
-                if (len - q < 2u) { has = false; q = len; }                      // :70 no match: stream ends
-                else {
-                    q += 2u;
-                    M = token & 15u;
-                    if (M == 15u) {
-                        bool eof = false;
-                        for (;;) {
-                            if (q >= len) { eof = true; break; }
-                            const uint32_t b = win.byte(q, lane); ++q;
-                            M += b; if (M > kMaxPosB) M = kMaxPosB;
-                            if (b != 255u) break;
-                        }
-                        if (eof) { perr = LZF_UNEXPECTED_END; break; }
-                    }
-                    M += 4u;
-                }
-                if (cap - o_run < L) { perr = LZF_OUT_CAPACITY; break; }
-                if (has && (uint64_t)o_run + L + M > limit) { perr = LZF_MEMORY_LIMIT_EXCEEDED; break; }   // :72-74
-                // too large for a batch?
-                if ((uint64_t)(o_run - ob0) + L + M > kSpanMax) {
-                    if (nseq == 0) { solo = true; s_src = src; s_L = L; s_M = M; s_has = has; s_offpos = src + L; p = q; }
-                    else p = tp;          // close the batch before this sequence
-                    break;
-                }
-                uint32_t fl = has ? 1u : 0u;
-                if (has && cap - (o_run + L) < M) fl |= 2u;                        // our buffer, lowest precedence
-                if (lane == nseq) { v_src = src; v_L = L; v_M = M; v_lo = o_run; v_fl = fl; }   // v_writelane
-                if (L > maxL) maxL = L;
-                o_run += L + M;
-                ++nseq;
-                p = q;
-                if (fl & 2u) break;       // nothing after a capacity failure matters
+                x = p;
+                // true exits never decrease along the stream, so a lane starts at the largest exit
+                // before it (a long literal run hands its exit to every region it skips at once)
+                uint32_t xm = x;
+#pragma unroll
+                for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t t = __shfl_up(xm, d); if (lane >= d && t > xm) xm = t; }
+                uint32_t nstart = __shfl_up(xm, 1);
+                if (lane == 0) nstart = cstart;
+                if (__all(nstart == start)) break;     // this pass ran from the true starts
+                start = nstart;
             }
-
+            // token ranks in stream order
+            const uint32_t incl_n = wave_incl_scan(n, lane);
+            const uint32_t rank0 = incl_n - n;
+            const uint32_t T = __builtin_amdgcn_readlane(incl_n, 63);
+            const bool cut = T > (uint32_t)TOKCAP;
+            const uint32_t Tc = cut ? (uint32_t)TOKCAP : T;
+            uint32_t cutpos = 0;
+            {   // record pass
+                uint32_t p = start, k = rank0;
+                while (p < rend && p < len) {
+                    uint32_t nx;
+                    if (!token_next(in, len, p, nx)) break;
+                    if (k < (uint32_t)TOKCAP) toks[k] = (uint16_t)(p - cstart);
+                    else if (k == (uint32_t)TOKCAP) cutpos = p;
+                    ++k; p = nx;
+                }
+            }
+            uint32_t cend;        // where the next chunk starts
+            int cerr = LZF_OK;    // UnexpectedEnd right after the listed tokens
+            if (cut) {
+                cend = __builtin_amdgcn_readlane(cutpos, first_lane(__ballot(rank0 <= (uint32_t)TOKCAP && rank0 + n > (uint32_t)TOKCAP)) & 63u);
+            } else {
+                cend = __builtin_amdgcn_readlane(x, 63);
+                if (__ballot(lerr)) cerr = LZF_UNEXPECTED_END;
+            }
             PHASE(0);
+
             // =====================================================================
-            // B. the batch: lane j < nseq owns sequence j
+            // B. batches of up to 64 sequences: lane j owns token tidx + j
             // =====================================================================
-            if (nseq > 0) {
-                const bool act = lane < nseq;
-                const uint32_t L = act ? v_L : 0u;
-                const uint32_t M = act ? v_M : 0u;
-                const uint32_t lo = v_lo, src = v_src;
+            uint32_t tidx = 0;
+            while (tidx < Tc && status == LZF_OK) {
+                const uint32_t ob0 = o;
+                const uint32_t nb_try = Tc - tidx < kWave ? Tc - tidx : kWave;
+                const bool act0 = lane < nb_try;
+                // ---- re-read the token (decompress.rs:61-71), per lane
+                uint32_t L = 0, M = 0, src = 0;
+                bool has = false;
+                if (act0) {
+                    const uint32_t tp = cstart + toks[tidx + lane];
+                    const uint32_t tok = in[tp];
+                    uint32_t q = tp + 1u;
+                    L = tok >> 4;
+                    if (L == 15u) { for (;;) { const uint32_t b = in[q++]; L += b; if (L > kMaxPosB) L = kMaxPosB; if (b != 255u) break; } }
+                    src = q; q += L;
+                    if (len - q >= 2u) {
+                        has = true; q += 2u;
+                        M = tok & 15u;
+                        if (M == 15u) { for (;;) { const uint32_t b = in[q++]; M += b; if (M > kMaxPosB) M = kMaxPosB; if (b != 255u) break; } }
+                        M += 4u;
+                    }
+                }
+                // ---- output positions
+                uint32_t tot = L + M; if (tot > kTotClamp || tot < L) tot = kTotClamp;
+                const uint32_t incl = wave_incl_scan(act0 ? tot : 0u, lane);
+                const uint32_t lo = ob0 + (incl - (act0 ? tot : 0u));
                 const uint32_t mo = lo + L;
-                const bool has = act && (v_fl & 1u);
+                const uint32_t c = first_lane(__ballot(act0 && incl > kSpanMax));
+                const uint32_t nb = c < nb_try ? c : nb_try;       // sequences in this batch
+
+                if (nb == 0u) {
+                    // =============================================================
+                    // C. solo sequence (larger than a batch): HBM -> HBM, then re-fill the ring
+                    // =============================================================
+                    const uint32_t s_L = __builtin_amdgcn_readlane(L, 0);
+                    const uint32_t s_M = __builtin_amdgcn_readlane(M, 0);
+                    const uint32_t s_src = __builtin_amdgcn_readlane(src, 0);
+                    const bool s_has = __builtin_amdgcn_readlane((uint32_t)has, 0) != 0u;
+                    if (cap - o < s_L) { status = LZF_OUT_CAPACITY; break; }
+                    if (s_has && (uint64_t)o + s_L + s_M > limit) { status = LZF_MEMORY_LIMIT_EXCEEDED; break; }   // :72-74
+                    const uint32_t o_before = o;
+                    wave_copy(out + o, in + s_src, s_L, lane);                           // literals :65-67
+                    o += s_L;
+                    if (s_has) {
+                        const uint32_t offset = (uint32_t)in[s_src + s_L] | ((uint32_t)in[s_src + s_L + 1u] << 8);
+                        uint32_t mlen = s_M;
+                        if (offset == 0u) { status = LZF_ZERO_DEDUP_OFFSET; break; }      // :83
+                        bool done = false;
+                        if (offset > o) {                                                 // :84-99
+                            const uint32_t need = offset - o;
+                            if (need > plen) { status = LZF_INVALID_DEDUP_OFFSET; break; }
+                            const uint32_t nn = need < mlen ? need : mlen;
+                            if (cap - o < nn) { status = LZF_OUT_CAPACITY; break; }
+                            wave_copy(out + o, prefix + (plen - need), nn, lane);
+                            o += nn; mlen -= nn;
+                            done = mlen == 0u;
+                        }
+                        if (!done) {
+                            if (cap - o < mlen) { status = LZF_OUT_CAPACITY; break; }
+                            const uint32_t src0 = o - offset;
+                            const uint32_t span = mlen < offset ? mlen : offset;
+                            if (src0 + span > safe) { wave_store_fence(); safe = o; }
+                            const uint8_t* hist = out + src0;
+                            uint8_t* dst = out + o;
+                            if (mlen <= offset) {
+                                wave_copy(dst, hist, mlen, lane);
+                            } else if (offset == 1u) {
+                                const uint32_t b = hist[0];
+                                const uint32_t b4 = b * 0x01010101u;
+                                const u32x4 v = {b4, b4, b4, b4};
+                                const uint32_t bulk = mlen & ~15u;
+                                for (uint32_t i = lane * 16u; i < bulk; i += kWave * 16u) st16(dst + i, v);
+                                if (lane < mlen - bulk) dst[bulk + lane] = (uint8_t)b;
+                            } else {
+                                uint32_t r = lane % offset;
+                                const uint32_t adv = kWave % offset;
+                                for (uint32_t i = lane; i < mlen; i += kWave) {
+                                    dst[i] = hist[r];
+                                    r += adv; if (r >= offset) r -= offset;
+                                }
+                            }
+                            o += mlen;
+                        }
+                    }
+                    // ring <- the tail of what was just written
+                    wave_store_fence(); safe = o;
+                    ring_fill((o - o_before > (uint32_t)RING) ? o - RING : o_before, o);
+                    tidx += 1u;
+                    continue;
+                }
+
+                const bool act = lane < nb;
+                has = has && act;
+                if (!act) { L = 0; M = 0; }
                 uint32_t off = 0;
                 if (has) off = (uint32_t)in[src + L] | ((uint32_t)in[src + L + 1u] << 8);
-                // ---- errors, first sequence in stream order wins
+                // ---- errors, first sequence in stream order wins; inside a sequence the reference's order
                 int code = LZF_OK;
-                if (has) {
-                    if (off == 0u) code = LZF_ZERO_DEDUP_OFFSET;                               // :83
-                    else if (off > mo && off - mo > plen) code = LZF_INVALID_DEDUP_OFFSET;    // :84-89
-                    else if (v_fl & 2u) code = LZF_OUT_CAPACITY;
+                if (act) {
+                    if (lo > cap || cap - lo < L) code = LZF_OUT_CAPACITY;                        // our buffer (literals)
+                    else if (has && (uint64_t)mo + M > limit) code = LZF_MEMORY_LIMIT_EXCEEDED;    // :72-74
+                    else if (has && off == 0u) code = LZF_ZERO_DEDUP_OFFSET;                       // :83
+                    else if (has && off > mo && off - mo > plen) code = LZF_INVALID_DEDUP_OFFSET;  // :84-89
+                    else if (has && cap - mo < M) code = LZF_OUT_CAPACITY;                         // our buffer (match)
                 }
                 const uint32_t e = first_lane(__ballot(code != LZF_OK));
                 if (e < 64u) { status = __builtin_amdgcn_readlane(code, e); break; }
-                if (perr != LZF_OK && !solo) {
-                    // the failing sequence comes after every lane of this batch; output content is
-                    // unspecified on error, so stop here
-                    status = perr; break;
-                }
-
                 PHASE(1);
+
                 // ---- literals -> ring (decompress.rs:65-67)
+                const uint32_t maxL = wave_max_u32(L);
                 if (maxL > 0u) {
                     const uint32_t Lc = L < kShort ? L : kShort;
                     const uint32_t maxLc = maxL < kShort ? maxL : kShort;
@@ -264,8 +360,8 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                         }
                     }
                 }
-
                 PHASE(2);
+
                 // ---- matches (copy_overlapping, decompress.rs:80-138)
                 const uint32_t near_lo = ob0 > kNearHist ? ob0 - kNearHist : 0u;
                 const uint32_t span = M < off ? M : off;                  // distinct source bytes
@@ -317,7 +413,6 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                     }
                 }
                 PHASE(3);
-                // near + slow: rounds against the high-water mark
                 unsigned long long unresolved = __ballot(is_near || is_slow);
                 const unsigned long long slow_mask = __ballot(is_slow);
                 // round 1 (lane-parallel): every near lane whose source lies below the first unresolved
@@ -391,66 +486,13 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 }
                 PHASE(4);
                 // ---- flush the batch ring -> HBM
-                o = o_run;
+                o = ob0 + __builtin_amdgcn_readlane(incl, (nb - 1u) & 63u);
                 ring_flush(ob0, o);
+                tidx += nb;
                 PHASE(5);
             }
-            if (perr != LZF_OK && !solo) { status = perr; break; }
-
-            // =====================================================================
-            // C. solo sequence (larger than a batch): HBM -> HBM, then re-fill the ring
-            // =====================================================================
-            if (solo) {
-                const uint32_t o_before = o;
-                wave_copy(out + o, in + s_src, s_L, lane);                           // literals
-                o += s_L;
-                if (s_has) {
-                    const uint32_t offset = win.byte(s_offpos, lane) | (win.byte(s_offpos + 1u, lane) << 8);
-                    uint32_t mlen = s_M;
-                    if (offset == 0u) { status = LZF_ZERO_DEDUP_OFFSET; break; }
-                    bool done = false;
-                    if (offset > o) {
-                        const uint32_t need = offset - o;
-                        if (need > plen) { status = LZF_INVALID_DEDUP_OFFSET; break; }
-                        const uint32_t n = need < mlen ? need : mlen;
-                        if (cap - o < n) { status = LZF_OUT_CAPACITY; break; }
-                        wave_copy(out + o, prefix + (plen - need), n, lane);
-                        o += n; mlen -= n;
-                        done = mlen == 0u;
-                    }
-                    if (!done) {
-                        if (cap - o < mlen) { status = LZF_OUT_CAPACITY; break; }
-                        const uint32_t src0 = o - offset;
-                        const uint32_t span = mlen < offset ? mlen : offset;
-                        if (src0 + span > safe) { wave_store_fence(); safe = o; }
-                        const uint8_t* hist = out + src0;
-                        uint8_t* dst = out + o;
-                        if (mlen <= offset) {
-                            wave_copy(dst, hist, mlen, lane);
-                        } else if (offset == 1u) {
-                            const uint32_t b = hist[0];
-                            const uint32_t b4 = b * 0x01010101u;
-                            const u32x4 v = {b4, b4, b4, b4};
-                            const uint32_t bulk = mlen & ~15u;
-                            for (uint32_t i = lane * 16u; i < bulk; i += kWave * 16u) st16(dst + i, v);
-                            if (lane < mlen - bulk) dst[bulk + lane] = (uint8_t)b;
-                        } else {
-                            uint32_t r = lane % offset;
-                            const uint32_t adv = kWave % offset;
-                            for (uint32_t i = lane; i < mlen; i += kWave) {
-                                dst[i] = hist[r];
-                                r += adv; if (r >= offset) r -= offset;
-                            }
-                        }
-                        o += mlen;
-                    }
-                }
-                // ring <- the tail of what was just written
-                wave_store_fence(); safe = o;
-                const uint32_t a = (o - o_before > (uint32_t)RING) ? o - RING : o_before;
-                ring_fill(a, o);
-                if (perr != LZF_OK) { status = perr; break; }
-            }
+            if (status == LZF_OK && cerr != LZF_OK) status = cerr;
+            cstart = cend;
         }
 #ifdef LZF_PHASE_TIMING
         for (int i = 0; i < 6; ++i) g_tph[i] = tph[i];
@@ -477,8 +519,8 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
     }
 }
 
-template __global__ void lzf_decompress_batched_kernel<16384>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
-template __global__ void lzf_decompress_batched_kernel<8192>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
-template __global__ void lzf_decompress_batched_kernel<32768>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+template __global__ void lzf_decompress_batched_kernel<16384, 256, 2048>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+template __global__ void lzf_decompress_batched_kernel<8192, 256, 2048>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+template __global__ void lzf_decompress_batched_kernel<8192, 128, 1024>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
 
 }  // namespace lzf
