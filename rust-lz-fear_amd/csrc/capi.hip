@@ -37,8 +37,8 @@ int ensure_device() {
 }
 
 // Kernel generation used by lzf_decompress_batch.  Tuning / A-B knob only (both generations
-// implement the same contract): LZF_DECOMPRESS_KERNEL = wave | batched16 (ring 16K, regions 256 B) | batched8 (8K, 256) |
-// batched8s (8K, 128).
+// implement the same contract): LZF_DECOMPRESS_KERNEL = wave | batched16 (ring 16K, regions 128 B) | batched8 (8K, 128) |
+// batched8s (8K, 64).
 int decompress_variant() {
     static const int v = [] {
         const char* e = getenv("LZF_DECOMPRESS_KERNEL");
@@ -93,9 +93,9 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     switch (decompress_variant()) {
         case 0: hipLaunchKernelGGL(lzf::lzf_decompress_wave_kernel, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
-        case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<8192, 256, 2048>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
-        case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<8192, 128, 1024>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
-        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<16384, 256, 2048>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
+        case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<8192, 128, 1024>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
+        case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<8192, 64, 512>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
+        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<16384, 128, 1024>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
     }
     HIP_TRY(hipGetLastError());
     return LZF_OK;

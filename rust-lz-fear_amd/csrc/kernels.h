@@ -8,9 +8,9 @@ __global__ void lzf_decompress_wave_kernel(const lzf_decompress_job* __restrict_
 template <int RING, int S, int TOKCAP>
 __global__ void lzf_decompress_batched_kernel(const lzf_decompress_job* __restrict__ jobs,
                                               lzf_job_result* __restrict__ results, uint32_t n_jobs);
-extern template __global__ void lzf_decompress_batched_kernel<16384, 256, 2048>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
-extern template __global__ void lzf_decompress_batched_kernel<8192, 256, 2048>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+extern template __global__ void lzf_decompress_batched_kernel<16384, 128, 1024>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
 extern template __global__ void lzf_decompress_batched_kernel<8192, 128, 1024>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+extern template __global__ void lzf_decompress_batched_kernel<8192, 64, 512>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
 template <int KIND>
 __global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
                                          lzf_job_result* __restrict__ results, uint32_t n_jobs);

@@ -14,13 +14,17 @@
 //   passes at worst; typical data needs 3-4).  A final pass records the token positions,
 //   compacted in stream order, into an LDS list.
 //
+//   The chunk's compressed bytes are staged in LDS first (one coalesced 16 B/lane pass), so every
+//   hop of the walks, every token re-read and every literal copy is an LDS access.
+//
 //   COPY (lane-parallel, batched).  64 consecutive sequences go to the 64 lanes.  The most
 //   recent RING bytes of output live in an LDS ring (ring index == output address mod RING, so
-//   16-byte chunks of the ring line up with 16-byte chunks of HBM).  Literals are staged
-//   through registers into the ring; "far" matches (older than the ring's intact history) are
-//   read back from HBM with two 16-byte loads per lane; "near" matches copy ring -> ring — all
-//   lanes at once when their source lies below the first unresolved match, the remainder
-//   strictly in stream order.  Overlapping matches use dst[t] = src[t mod offset], whose reads
+//   16-byte chunks of the ring line up with 16-byte chunks of HBM).  A lane moves its literal run
+//   and its match with "two-ended" pieces (first and last 8/4/2 bytes, any alignment: gfx950
+//   executes misaligned DS accesses), so a run of up to 32 bytes costs at most 4 LDS reads and
+//   4 LDS writes.  "far" matches (older than the ring's intact history) are read back from HBM;
+//   "near" matches copy ring -> ring — all lanes at once when their source lies below the first
+//   unresolved match, the remainder strictly in stream order.  Overlapping matches use dst[t] = src[t mod offset], whose reads
 //   all precede the match.  LDS executes one wave's accesses in order, so no barrier or wait
 //   separates dependent copies.  The finished batch is flushed ring -> HBM with aligned
 //   16-byte stores: every output byte is written to HBM exactly once, coalesced.
@@ -40,52 +44,45 @@ constexpr uint32_t kMaxPosB = 0x7FFFFF00u;
 constexpr uint32_t kShort = 32;          // bytes a lane moves by itself; longer runs are cooperative
 constexpr uint32_t kTotClamp = 1u << 25; // per-sequence output clamp inside the position scan
 
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = __shfl_xor(v, m); v = o > v ? o : v; }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t t = __shfl_up(v, d); if (lane >= d) v += t; }
-    return v;
-}
-
-// 4 input bytes at pos (pos < len), never reading at or beyond len
-__device__ __forceinline__ uint32_t safe_ld4(const uint8_t* in, uint32_t len, uint32_t pos) {
-    if (pos + 4u <= len) return ld4(in + pos);
-    uint32_t v = 0;
-    for (uint32_t i = 0; pos + i < len; ++i) v |= (uint32_t)in[pos + i] << (8u * i);
-    return v;
-}
-
-// One token of the stream at p (p < len): position of the next token, or an error.
-// decompress.rs:61-71 without the copies.  Returns false on UnexpectedEnd.
-__device__ __forceinline__ bool token_next(const uint8_t* __restrict__ in, uint32_t len, uint32_t p, uint32_t& next) {
-    const uint32_t tok = in[p];
-    uint32_t q = p + 1u;
-    uint32_t L = tok >> 4;
-    if (L == 15u) {
-        for (;;) {
-            if (q >= len) return false;
-            const uint32_t b = in[q++];
-            L += b; if (L > kMaxPosB) L = kMaxPosB;
-            if (b != 255u) break;
-        }
+// Exact per-lane copy of n (1..32) bytes between two non-overlapping LDS byte ranges, neither of
+// which wraps: two-ended pieces (first/last 8, 4 or 2 bytes), at most 4 reads + 4 writes.
+__device__ __forceinline__ void put_small_lds(uint32_t dst, uint32_t srca, uint32_t n) {
+    if (n >= 8u) {
+        const bool big = n > 16u;
+        uint64_t v0, v1, v2, v3;
+        lds_ld64x4(srca, big ? srca + 8u : srca, big ? srca + n - 16u : srca, srca + n - 8u, v0, v1, v2, v3);
+        lds_st64(dst, v0);
+        if (big) { lds_st64(dst + 8u, v1); lds_st64(dst + n - 16u, v2); }
+        lds_st64(dst + n - 8u, v3);
+    } else if (n >= 4u) {
+        uint32_t v0, v1; lds_ld32x2(srca, srca + n - 4u, v0, v1);
+        lds_st32(dst, v0); lds_st32(dst + n - 4u, v1);
+    } else if (n >= 2u) {
+        uint32_t v0, v1; lds_ld16x2(srca, srca + n - 2u, v0, v1);
+        lds_st16(dst, v0); lds_st16(dst + n - 2u, v1);
+    } else if (n == 1u) {
+        lds_st8(dst, lds_ld8(srca));
     }
-    if (len - q < L) return false;                    // :67 read_exact
-    q += L;
-    if (len - q < 2u) { next = len; return true; }    // :70 read_u16 fails: last literals
-    q += 2u;
-    if ((tok & 15u) == 15u) {
-        for (;;) {
-            if (q >= len) return false;
-            const uint32_t b = in[q++];
-            if (b != 255u) break;
-        }
+}
+// Same, source in global memory (unaligned loads; reads exactly [g, g+n)).
+__device__ __forceinline__ void put_small_glb(uint32_t dst, const uint8_t* g, uint32_t n) {
+    if (n >= 8u) {
+        const bool big = n > 16u;
+        const uint64_t v0 = ld8(g), v3 = ld8(g + n - 8u);
+        uint64_t v1 = 0, v2 = 0;
+        if (big) { v1 = ld8(g + 8u); v2 = ld8(g + n - 16u); }
+        lds_st64(dst, v0);
+        if (big) { lds_st64(dst + 8u, v1); lds_st64(dst + n - 16u, v2); }
+        lds_st64(dst + n - 8u, v3);
+    } else if (n >= 4u) {
+        const uint32_t v0 = ld4(g), v1 = ld4(g + n - 4u);
+        lds_st32(dst, v0); lds_st32(dst + n - 4u, v1);
+    } else if (n >= 2u) {
+        const uint32_t v0 = reinterpret_cast<const U2B*>(g)->v, v1 = reinterpret_cast<const U2B*>(g + n - 2u)->v;
+        lds_st16(dst, v0); lds_st16(dst + n - 2u, v1);
+    } else if (n == 1u) {
+        lds_st8(dst, g[0]);
     }
-    next = q;
-    return true;
 }
 
 }  // namespace
@@ -96,8 +93,12 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
     constexpr uint32_t kMask = RING - 1;
     constexpr uint32_t kSpanMax = RING / 4;            // output bytes one batch may produce
     constexpr uint32_t kNearHist = RING - kSpanMax;    // history before the batch that stays intact in the ring
-    static_assert(S * 64 <= 65536, "token positions are stored as u16 offsets into the chunk");
+    constexpr uint32_t kChunk = 64u * S;               // compressed bytes whose tokens one parse covers
+    constexpr uint32_t kCB = kChunk + 64u;             // staged bytes: the chunk + room for token bodies
+    static_assert(kChunk <= 65536, "token positions are stored as u16 offsets into the chunk");
+    static_assert(kCB % 16 == 0, "chunk buffer is filled in 16-byte pieces");
     __shared__ __attribute__((aligned(16))) uint8_t ring[RING];
+    __shared__ __attribute__((aligned(16))) uint8_t cbuf[kCB];
     __shared__ uint16_t toks[TOKCAP];
 
     const uint32_t jid = blockIdx.x;
@@ -122,6 +123,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
         const uint32_t cap = job.out_cap > kMaxPosB ? kMaxPosB : (uint32_t)job.out_cap;
         const uint64_t limit = job.output_limit;
         const uint32_t rb = (uint32_t)(reinterpret_cast<uintptr_t>(out) & 15u);   // ring bias
+        const uint32_t ring_a = lds_addr(ring), cbuf_a = lds_addr(cbuf);
 #define RIDX(x) (((x) + rb) & kMask)
 
         // ring <- out[a, b)   (b - a <= RING; caller made out[a,b) visible)
@@ -160,6 +162,59 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
         uint32_t cstart = 0;                 // a true token position (or len)
         while (cstart < len && status == LZF_OK) {
             // =====================================================================
+            // A0. stage in[cstart, cstart + kCB) in LDS
+            // =====================================================================
+            {
+                const uint32_t avail = len - cstart < kCB ? len - cstart : kCB;
+                const uint8_t* g = in + cstart;
+#pragma unroll 1
+                for (uint32_t base = 0; base < kCB; base += 4u * 1024u) {
+                    u32x4 v[4];
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; ++k) {
+                        const uint32_t i = base + k * 1024u + lane * 16u;
+                        v[k] = u32x4{0, 0, 0, 0};
+                        if (i + 16u <= avail) v[k] = ld16(g + i);
+                        else if (i < avail) { for (uint32_t t = 0; i + t < avail; ++t) v[k][(t >> 2) & 3u] |= (uint32_t)g[i + t] << ((t & 3u) * 8u); }
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < 4u; ++k) {
+                        const uint32_t i = base + k * 1024u + lane * 16u;
+                        if (i < kCB) *reinterpret_cast<u32x4*>(&cbuf[i]) = v[k];
+                    }
+                }
+            }
+            // byte of the input at absolute position q >= cstart
+            auto rdb = [&](uint32_t q) -> uint32_t { const uint32_t r = q - cstart; return r < kCB ? (uint32_t)cbuf[r] : (uint32_t)in[q]; };
+            // One token at p (p < len): position of the next token; false on UnexpectedEnd.
+            // decompress.rs:61-71 without the copies.
+            auto token_next = [&](uint32_t p, uint32_t& next) -> bool {
+                const uint32_t tok = rdb(p);
+                uint32_t q = p + 1u;
+                uint32_t L = tok >> 4;
+                if (L == 15u) {
+                    for (;;) {
+                        if (q >= len) return false;
+                        const uint32_t b = rdb(q); ++q;
+                        L += b; if (L > kMaxPosB) L = kMaxPosB;
+                        if (b != 255u) break;
+                    }
+                }
+                if (len - q < L) return false;                    // :67 read_exact
+                q += L;
+                if (len - q < 2u) { next = len; return true; }    // :70 read_u16 fails: last literals
+                q += 2u;
+                if ((tok & 15u) == 15u) {
+                    for (;;) {
+                        if (q >= len) return false;
+                        const uint32_t b = rdb(q); ++q;
+                        if (b != 255u) break;
+                    }
+                }
+                next = q;
+                return true;
+            };
+            // =====================================================================
             // A. speculative lane-parallel parse of one chunk: regions [cstart + i*S, +S)
             // =====================================================================
             const uint32_t rbeg = cstart + lane * (uint32_t)S;
@@ -172,22 +227,18 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 n = 0; lerr = false;
                 while (p < rend && p < len) {
                     uint32_t nx;
-                    if (!token_next(in, len, p, nx)) { lerr = true; p = len; break; }
+                    if (!token_next(p, nx)) { lerr = true; p = len; break; }
                     ++n; p = nx;
                 }
                 x = p;
                 // true exits never decrease along the stream, so a lane starts at the largest exit
                 // before it (a long literal run hands its exit to every region it skips at once)
-                uint32_t xm = x;
-#pragma unroll
-                for (uint32_t d = 1; d < 64u; d <<= 1) { const uint32_t t = __shfl_up(xm, d); if (lane >= d && t > xm) xm = t; }
-                uint32_t nstart = __shfl_up(xm, 1);
-                if (lane == 0) nstart = cstart;
+                const uint32_t nstart = wave_prev(wave_scan_max(x), cstart);
                 if (__all(nstart == start)) break;     // this pass ran from the true starts
                 start = nstart;
             }
             // token ranks in stream order
-            const uint32_t incl_n = wave_incl_scan(n, lane);
+            const uint32_t incl_n = wave_scan_add(n);
             const uint32_t rank0 = incl_n - n;
             const uint32_t T = __builtin_amdgcn_readlane(incl_n, 63);
             const bool cut = T > (uint32_t)TOKCAP;
@@ -197,7 +248,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 uint32_t p = start, k = rank0;
                 while (p < rend && p < len) {
                     uint32_t nx;
-                    if (!token_next(in, len, p, nx)) break;
+                    if (!token_next(p, nx)) break;
                     if (k < (uint32_t)TOKCAP) toks[k] = (uint16_t)(p - cstart);
                     else if (k == (uint32_t)TOKCAP) cutpos = p;
                     ++k; p = nx;
@@ -226,21 +277,21 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 bool has = false;
                 if (act0) {
                     const uint32_t tp = cstart + toks[tidx + lane];
-                    const uint32_t tok = in[tp];
+                    const uint32_t tok = rdb(tp);
                     uint32_t q = tp + 1u;
                     L = tok >> 4;
-                    if (L == 15u) { for (;;) { const uint32_t b = in[q++]; L += b; if (L > kMaxPosB) L = kMaxPosB; if (b != 255u) break; } }
+                    if (L == 15u) { for (;;) { const uint32_t b = rdb(q); ++q; L += b; if (L > kMaxPosB) L = kMaxPosB; if (b != 255u) break; } }
                     src = q; q += L;
                     if (len - q >= 2u) {
                         has = true; q += 2u;
                         M = tok & 15u;
-                        if (M == 15u) { for (;;) { const uint32_t b = in[q++]; M += b; if (M > kMaxPosB) M = kMaxPosB; if (b != 255u) break; } }
+                        if (M == 15u) { for (;;) { const uint32_t b = rdb(q); ++q; M += b; if (M > kMaxPosB) M = kMaxPosB; if (b != 255u) break; } }
                         M += 4u;
                     }
                 }
                 // ---- output positions
                 uint32_t tot = L + M; if (tot > kTotClamp || tot < L) tot = kTotClamp;
-                const uint32_t incl = wave_incl_scan(act0 ? tot : 0u, lane);
+                const uint32_t incl = wave_scan_add(act0 ? tot : 0u);
                 const uint32_t lo = ob0 + (incl - (act0 ? tot : 0u));
                 const uint32_t mo = lo + L;
                 const uint32_t c = first_lane(__ballot(act0 && incl > kSpanMax));
@@ -311,7 +362,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 has = has && act;
                 if (!act) { L = 0; M = 0; }
                 uint32_t off = 0;
-                if (has) off = (uint32_t)in[src + L] | ((uint32_t)in[src + L + 1u] << 8);
+                if (has) off = rdb(src + L) | (rdb(src + L + 1u) << 8);
                 // ---- errors, first sequence in stream order wins; inside a sequence the reference's order
                 int code = LZF_OK;
                 if (act) {
@@ -326,37 +377,33 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 PHASE(1);
 
                 // ---- literals -> ring (decompress.rs:65-67)
-                const uint32_t maxL = wave_max_u32(L);
-                if (maxL > 0u) {
-                    const uint32_t Lc = L < kShort ? L : kShort;
-                    const uint32_t maxLc = maxL < kShort ? maxL : kShort;
-                    uint32_t d[8];
-#pragma unroll
-                    for (uint32_t k = 0; k < 8u; ++k) {
-                        d[k] = 0u;
-                        if (4u * k < maxLc) { if (4u * k < Lc) d[k] = safe_ld4(in, len, src + 4u * k); }
+                if (__ballot(L > 0u)) {
+                    const uint32_t n1 = L < kShort ? L : kShort;            // the lane's own share
+                    const uint32_t ri = RIDX(lo);
+                    if (n1 > 0u) {
+                        if (ri + n1 > (uint32_t)RING) {                     // wraps around the ring: bytes
+                            for (uint32_t t = 0; t < n1; ++t) ring[RIDX(lo + t)] = (uint8_t)rdb(src + t);
+                        } else if (src - cstart + n1 <= kCB) {
+                            put_small_lds(ring_a + ri, cbuf_a + (src - cstart), n1);
+                        } else {
+                            put_small_glb(ring_a + ri, in + src, n1);
+                        }
                     }
-#pragma unroll
-                    for (uint32_t t = 0; t < kShort; ++t) {
-                        if (t < maxLc) { if (t < Lc) ring[RIDX(lo + t)] = (uint8_t)(d[t >> 2] >> ((t & 3u) * 8u)); }
-                    }
-                    if (maxL > kShort) {
-                        for (unsigned long long m = __ballot(L > kShort); m; m &= m - 1ull) {
-                            const uint32_t j = (uint32_t)__builtin_ctzll(m);
-                            const uint32_t jl = __builtin_amdgcn_readlane(L, j);
-                            const uint32_t js = __builtin_amdgcn_readlane(src, j);
-                            const uint32_t jo = __builtin_amdgcn_readlane(lo, j);
-                            for (uint32_t i = kShort + lane; i < jl; i += 4u * kWave) {
-                                const uint32_t i1 = i + kWave, i2 = i + 2u * kWave, i3 = i + 3u * kWave;
-                                const uint8_t b0 = in[js + i];
-                                const uint8_t b1 = i1 < jl ? in[js + i1] : (uint8_t)0;
-                                const uint8_t b2 = i2 < jl ? in[js + i2] : (uint8_t)0;
-                                const uint8_t b3 = i3 < jl ? in[js + i3] : (uint8_t)0;
-                                ring[RIDX(jo + i)] = b0;
-                                if (i1 < jl) ring[RIDX(jo + i1)] = b1;
-                                if (i2 < jl) ring[RIDX(jo + i2)] = b2;
-                                if (i3 < jl) ring[RIDX(jo + i3)] = b3;
-                            }
+                    for (unsigned long long m = __ballot(L > kShort); m; m &= m - 1ull) {      // long runs: all lanes
+                        const uint32_t j = (uint32_t)__builtin_ctzll(m);
+                        const uint32_t jl = __builtin_amdgcn_readlane(L, j);
+                        const uint32_t js = __builtin_amdgcn_readlane(src, j);
+                        const uint32_t jo = __builtin_amdgcn_readlane(lo, j);
+                        for (uint32_t i = kShort + lane; i < jl; i += 4u * kWave) {
+                            const uint32_t i1 = i + kWave, i2 = i + 2u * kWave, i3 = i + 3u * kWave;
+                            const uint8_t b0 = in[js + i];
+                            const uint8_t b1 = i1 < jl ? in[js + i1] : (uint8_t)0;
+                            const uint8_t b2 = i2 < jl ? in[js + i2] : (uint8_t)0;
+                            const uint8_t b3 = i3 < jl ? in[js + i3] : (uint8_t)0;
+                            ring[RIDX(jo + i)] = b0;
+                            if (i1 < jl) ring[RIDX(jo + i1)] = b1;
+                            if (i2 < jl) ring[RIDX(jo + i2)] = b2;
+                            if (i3 < jl) ring[RIDX(jo + i3)] = b3;
                         }
                     }
                 }
@@ -370,75 +417,54 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 const bool is_near = has && !from_prefix && s0 >= near_lo;
                 const bool is_far = has && !from_prefix && s0 + span <= near_lo;
                 const bool is_slow = has && !is_near && !is_far;          // prefix or straddling
+                const uint32_t mi = RIDX(mo);
+                const bool mwrap = mi + M > (uint32_t)RING;               // destination wraps around the ring
                 // HBM visibility of what far / slow lanes read back
                 {
                     uint32_t need = 0;
-                    if (is_far) need = s0 + (M > kShort ? M : kShort);
+                    if (is_far) need = s0 + M;
                     if (is_slow && !from_prefix) need = near_lo;
                     if (is_slow && from_prefix && M > off - mo) need = near_lo;
                     if (need > ob0) need = ob0;
-                    if (wave_max_u32(need) > safe) { wave_store_fence(); safe = ob0; }
+                    if (__ballot(need > safe)) { wave_store_fence(); safe = ob0; }
                 }
-                // far, short: two 16-byte loads per lane, bytes into the ring
-                if (__ballot(is_far && M <= kShort)) {
-                    u32x4 f0 = {0, 0, 0, 0}, f1 = {0, 0, 0, 0};
-                    const bool go = is_far && M <= kShort;
-                    if (go) { f0 = ld16(out + s0); if (M > 16u) f1 = ld16(out + s0 + 16u); }
-                    const uint32_t fm = go ? M : 0u;
-                    const uint32_t maxfm = wave_max_u32(fm);
-#pragma unroll
-                    for (uint32_t t = 0; t < kShort; ++t) {
-                        if (t < maxfm) {
-                            const uint32_t dw = t < 16u ? f0[(t >> 2) & 3u] : f1[(t >> 2) & 3u];
-                            if (t < fm) ring[RIDX(mo + t)] = (uint8_t)(dw >> ((t & 3u) * 8u));
-                        }
+                // far (never overlapping: offset > ring history > length): HBM -> ring
+                if (__ballot(is_far)) {
+                    if (is_far && M <= kShort) {
+                        if (mwrap) { for (uint32_t t = 0; t < M; ++t) ring[RIDX(mo + t)] = out[s0 + t]; }
+                        else put_small_glb(ring_a + mi, out + s0, M);
                     }
-                }
-                // far, long: cooperative HBM -> ring (never overlapping: offset > ring history > length)
-                for (unsigned long long m = __ballot(is_far && M > kShort); m; m &= m - 1ull) {
-                    const uint32_t j = (uint32_t)__builtin_ctzll(m);
-                    const uint32_t jm = __builtin_amdgcn_readlane(M, j);
-                    const uint32_t js = __builtin_amdgcn_readlane(s0, j);
-                    const uint32_t jo = __builtin_amdgcn_readlane(mo, j);
-                    for (uint32_t i = lane; i < jm; i += 4u * kWave) {
-                        const uint32_t i1 = i + kWave, i2 = i + 2u * kWave, i3 = i + 3u * kWave;
-                        const uint8_t b0 = out[js + i];
-                        const uint8_t b1 = i1 < jm ? out[js + i1] : (uint8_t)0;
-                        const uint8_t b2 = i2 < jm ? out[js + i2] : (uint8_t)0;
-                        const uint8_t b3 = i3 < jm ? out[js + i3] : (uint8_t)0;
-                        ring[RIDX(jo + i)] = b0;
-                        if (i1 < jm) ring[RIDX(jo + i1)] = b1;
-                        if (i2 < jm) ring[RIDX(jo + i2)] = b2;
-                        if (i3 < jm) ring[RIDX(jo + i3)] = b3;
+                    for (unsigned long long m = __ballot(is_far && M > kShort); m; m &= m - 1ull) {
+                        const uint32_t j = (uint32_t)__builtin_ctzll(m);
+                        const uint32_t jm = __builtin_amdgcn_readlane(M, j);
+                        const uint32_t js = __builtin_amdgcn_readlane(s0, j);
+                        const uint32_t jo = __builtin_amdgcn_readlane(mo, j);
+                        for (uint32_t i = lane; i < jm; i += 4u * kWave) {
+                            const uint32_t i1 = i + kWave, i2 = i + 2u * kWave, i3 = i + 3u * kWave;
+                            const uint8_t b0 = out[js + i];
+                            const uint8_t b1 = i1 < jm ? out[js + i1] : (uint8_t)0;
+                            const uint8_t b2 = i2 < jm ? out[js + i2] : (uint8_t)0;
+                            const uint8_t b3 = i3 < jm ? out[js + i3] : (uint8_t)0;
+                            ring[RIDX(jo + i)] = b0;
+                            if (i1 < jm) ring[RIDX(jo + i1)] = b1;
+                            if (i2 < jm) ring[RIDX(jo + i2)] = b2;
+                            if (i3 < jm) ring[RIDX(jo + i3)] = b3;
+                        }
                     }
                 }
                 PHASE(3);
                 unsigned long long unresolved = __ballot(is_near || is_slow);
                 const unsigned long long slow_mask = __ballot(is_slow);
-                // round 1 (lane-parallel): every near lane whose source lies below the first unresolved
-                // match start H — on typical data that is almost all of them
+                // round 1 (lane-parallel): every near, non-overlapping, short match whose source lies
+                // below the first unresolved match start H — on typical data almost all of them
                 if (unresolved) {
                     const uint32_t f = (uint32_t)__builtin_ctzll(unresolved);
                     const uint32_t H = __builtin_amdgcn_readlane(mo, f);      // everything below H is final
-                    const bool ready = is_near && (s0 + span <= H) && !((slow_mask >> f) & 1ull);
-                    const unsigned long long rmask = __ballot(ready);
-                    const uint32_t cnt = (ready && M <= kShort) ? M : 0u;
-                    const uint32_t maxcnt = wave_max_u32(cnt);
-                    uint32_t r = 0;
-                    for (uint32_t t0 = 0; t0 < maxcnt; t0 += 8u) {
-                        uint8_t b[8];
-#pragma unroll
-                        for (uint32_t k = 0; k < 8u; ++k) {
-                            b[k] = 0;
-                            if (t0 + k < cnt) { b[k] = ring[RIDX(s0 + r)]; ++r; if (r == off) r = 0u; }
-                        }
-#pragma unroll
-                        for (uint32_t k = 0; k < 8u; ++k) {
-                            if (t0 + k < cnt) ring[RIDX(mo + t0 + k)] = b[k];
-                        }
-                    }
-                    // long ready lanes go through the in-order loop below (their sources are final)
-                    unresolved &= ~(rmask & __ballot(M <= kShort));
+                    const uint32_t si = RIDX(s0);
+                    const bool fast = is_near && (s0 + span <= H) && M <= off && M <= kShort &&
+                                      !mwrap && !(si + M > (uint32_t)RING);
+                    if (fast) put_small_lds(ring_a + mi, ring_a + si, M);
+                    unresolved &= ~__ballot(fast);
                 }
                 // the rest strictly in stream order, one sequence at a time, all lanes on it
                 while (unresolved) {
@@ -519,8 +545,8 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
     }
 }
 
-template __global__ void lzf_decompress_batched_kernel<16384, 256, 2048>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
-template __global__ void lzf_decompress_batched_kernel<8192, 256, 2048>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+template __global__ void lzf_decompress_batched_kernel<16384, 128, 1024>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
 template __global__ void lzf_decompress_batched_kernel<8192, 128, 1024>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+template __global__ void lzf_decompress_batched_kernel<8192, 64, 512>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
 
 }  // namespace lzf

@@ -51,3 +51,54 @@ __device__ __forceinline__ void wave_copy(uint8_t* __restrict__ dst, const uint8
 }
 
 }  // namespace lzf
+
+// ---------------------------------------------------------------------------------------------
+// wave64 scans on DPP (row_shr 1/2/4/8, row_bcast 15/31): no LDS traffic, ~6 VALU each
+// ---------------------------------------------------------------------------------------------
+namespace lzf {
+#define LZF_DPP(old, x, ctrl, rmask) (uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(x), ctrl, rmask, 0xf, false)
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t v) {     // inclusive prefix sum over lanes
+    v += LZF_DPP(0, v, 0x111, 0xf); v += LZF_DPP(0, v, 0x112, 0xf);
+    v += LZF_DPP(0, v, 0x114, 0xf); v += LZF_DPP(0, v, 0x118, 0xf);
+    v += LZF_DPP(0, v, 0x142, 0xa); v += LZF_DPP(0, v, 0x143, 0xc);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t v) {     // inclusive prefix max over lanes
+    uint32_t t;
+    t = LZF_DPP(0, v, 0x111, 0xf); v = t > v ? t : v; t = LZF_DPP(0, v, 0x112, 0xf); v = t > v ? t : v;
+    t = LZF_DPP(0, v, 0x114, 0xf); v = t > v ? t : v; t = LZF_DPP(0, v, 0x118, 0xf); v = t > v ? t : v;
+    t = LZF_DPP(0, v, 0x142, 0xa); v = t > v ? t : v; t = LZF_DPP(0, v, 0x143, 0xc); v = t > v ? t : v;
+    return v;
+}
+// value of the previous lane (lane 0 gets `first`)
+__device__ __forceinline__ uint32_t wave_prev(uint32_t v, uint32_t first) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)first, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Byte-addressed LDS accesses of 2/4/8 bytes at ANY alignment.  gfx950 executes misaligned DS
+// accesses correctly (about 2x the cost of an aligned one; tools/lds_unaligned_test.hip), but
+// hipcc never emits them for under-aligned types (it splits into bytes), hence inline asm.
+// `a` is the LDS byte address (low 32 bits of a __shared__ pointer).  The load forms wait for
+// their own data (s_waitcnt lgkmcnt(0)) because hipcc does not count asm memory operations.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)reinterpret_cast<uintptr_t>(p); }
+__device__ __forceinline__ void lds_st8(uint32_t a, uint32_t v) { asm volatile("ds_write_b8 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_st16(uint32_t a, uint32_t v) { asm volatile("ds_write_b16 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_st32(uint32_t a, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_st64(uint32_t a, uint64_t v) { asm volatile("ds_write_b64 %0, %1" ::"v"(a), "v"(v) : "memory"); }
+__device__ __forceinline__ void lds_ld64x4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3,
+                                           uint64_t& v0, uint64_t& v1, uint64_t& v2, uint64_t& v3) {
+    asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %5\n\tds_read_b64 %2, %6\n\tds_read_b64 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+}
+__device__ __forceinline__ void lds_ld32x2(uint32_t a0, uint32_t a1, uint32_t& v0, uint32_t& v1) {
+    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(a0), "v"(a1) : "memory");
+}
+__device__ __forceinline__ void lds_ld16x2(uint32_t a0, uint32_t a1, uint32_t& v0, uint32_t& v1) {
+    asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(a0), "v"(a1) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_ld8(uint32_t a) {
+    uint32_t v; asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory"); return v;
+}
+}  // namespace lzf
