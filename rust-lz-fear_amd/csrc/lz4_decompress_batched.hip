@@ -219,11 +219,21 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
             // =====================================================================
             const uint32_t rbeg = cstart + lane * (uint32_t)S;
             const uint32_t rend = rbeg + (uint32_t)S;
-            uint32_t start = lane == 0 ? cstart : (rbeg < len ? rbeg : len);
+            // First guess: walk in from the previous region's start (for lane 1 that is a true token),
+            // so that the chain has usually re-synchronised by the time it enters the lane's region.
+            uint32_t start = lane == 0 ? cstart : rbeg - (uint32_t)S;
             uint32_t x = 0, n = 0;
             bool lerr = false;
             for (uint32_t pass = 0; pass < 70u; ++pass) {
                 uint32_t p = start;
+                if (pass == 0u) {                                  // warm-up: tokens before the region do not count
+                    while (p < rbeg && p < len) {
+                        uint32_t nx;
+                        if (!token_next(p, nx)) { p = len; break; }
+                        p = nx;
+                    }
+                    start = p;
+                }
                 n = 0; lerr = false;
                 while (p < rend && p < len) {
                     uint32_t nx;
@@ -466,47 +476,59 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                     if (fast) put_small_lds(ring_a + mi, ring_a + si, M);
                     unresolved &= ~__ballot(fast);
                 }
-                // the rest strictly in stream order, one sequence at a time, all lanes on it
-                while (unresolved) {
-                    const uint32_t f = (uint32_t)__builtin_ctzll(unresolved);
-                    unresolved &= unresolved - 1ull;
-                    if ((slow_mask >> f) & 1ull) {
-                        // prefix / straddling source: one lane, byte-serial, three sources
-                        if (lane == f) {
-                            for (uint32_t t = 0; t < M; ++t) {
-                                uint8_t v;
-                                if (off > mo + t) v = prefix[plen - (off - mo) + t];                // :91-93
-                                else {
-                                    const uint32_t s = mo + t - off;
-                                    v = s < near_lo ? out[s] : ring[RIDX(s)];
+                // the rest strictly in stream order.  LDS runs one wave's accesses in order, so a dependent
+                // copy only has to be issued after the copies it reads from: the owning lane moves a short
+                // non-overlapping match by itself (two-ended pieces), everything else is cooperative.
+                {
+                    const uint32_t si = RIDX(s0);
+                    const bool solo_ok = is_near && M <= off && M <= kShort && !mwrap && !(si + M > (uint32_t)RING);
+                    const unsigned long long solo_mask = __ballot(solo_ok);
+                    while (unresolved) {
+                        const uint32_t f = (uint32_t)__builtin_ctzll(unresolved);
+                        const unsigned long long bit = 1ull << f;
+                        unresolved &= ~bit;
+                        if (solo_mask & bit) {
+                            if (lane == f) put_small_lds(ring_a + mi, ring_a + si, M);
+                            continue;
+                        }
+                        if (slow_mask & bit) {
+                            // prefix / straddling source: one lane, byte-serial, three sources
+                            if (lane == f) {
+                                for (uint32_t t = 0; t < M; ++t) {
+                                    uint8_t v;
+                                    if (off > mo + t) v = prefix[plen - (off - mo) + t];                // :91-93
+                                    else {
+                                        const uint32_t s = mo + t - off;
+                                        v = s < near_lo ? out[s] : ring[RIDX(s)];
+                                    }
+                                    ring[RIDX(mo + t)] = v;
                                 }
-                                ring[RIDX(mo + t)] = v;
                             }
+                            continue;
                         }
-                        continue;
-                    }
-                    const uint32_t jm = __builtin_amdgcn_readlane(M, f);
-                    const uint32_t js = __builtin_amdgcn_readlane(s0, f);
-                    const uint32_t jo = __builtin_amdgcn_readlane(mo, f);
-                    const uint32_t joff = __builtin_amdgcn_readlane(off, f);
-                    if (jm <= joff) {                                   // non-overlapping: 4 bytes in flight per lane
-                        for (uint32_t i = lane; i < jm; i += 4u * kWave) {
-                            const uint32_t i1 = i + kWave, i2 = i + 2u * kWave, i3 = i + 3u * kWave;
-                            const uint8_t b0 = ring[RIDX(js + i)];
-                            const uint8_t b1 = i1 < jm ? ring[RIDX(js + i1)] : (uint8_t)0;
-                            const uint8_t b2 = i2 < jm ? ring[RIDX(js + i2)] : (uint8_t)0;
-                            const uint8_t b3 = i3 < jm ? ring[RIDX(js + i3)] : (uint8_t)0;
-                            ring[RIDX(jo + i)] = b0;
-                            if (i1 < jm) ring[RIDX(jo + i1)] = b1;
-                            if (i2 < jm) ring[RIDX(jo + i2)] = b2;
-                            if (i3 < jm) ring[RIDX(jo + i3)] = b3;
-                        }
-                    } else {                                            // overlapping: period-`offset` addressing
-                        uint32_t rr = lane % joff;
-                        const uint32_t adv = kWave % joff;
-                        for (uint32_t i = lane; i < jm; i += kWave) {
-                            ring[RIDX(jo + i)] = ring[RIDX(js + rr)];
-                            rr += adv; if (rr >= joff) rr -= joff;
+                        const uint32_t jm = __builtin_amdgcn_readlane(M, f);
+                        const uint32_t js = __builtin_amdgcn_readlane(s0, f);
+                        const uint32_t jo = __builtin_amdgcn_readlane(mo, f);
+                        const uint32_t joff = __builtin_amdgcn_readlane(off, f);
+                        if (jm <= joff) {                                   // non-overlapping: 4 bytes in flight per lane
+                            for (uint32_t i = lane; i < jm; i += 4u * kWave) {
+                                const uint32_t i1 = i + kWave, i2 = i + 2u * kWave, i3 = i + 3u * kWave;
+                                const uint8_t b0 = ring[RIDX(js + i)];
+                                const uint8_t b1 = i1 < jm ? ring[RIDX(js + i1)] : (uint8_t)0;
+                                const uint8_t b2 = i2 < jm ? ring[RIDX(js + i2)] : (uint8_t)0;
+                                const uint8_t b3 = i3 < jm ? ring[RIDX(js + i3)] : (uint8_t)0;
+                                ring[RIDX(jo + i)] = b0;
+                                if (i1 < jm) ring[RIDX(jo + i1)] = b1;
+                                if (i2 < jm) ring[RIDX(jo + i2)] = b2;
+                                if (i3 < jm) ring[RIDX(jo + i3)] = b3;
+                            }
+                        } else {                                            // overlapping: period-`offset` addressing
+                            uint32_t rr = lane % joff;
+                            const uint32_t adv = kWave % joff;
+                            for (uint32_t i = lane; i < jm; i += kWave) {
+                                ring[RIDX(jo + i)] = ring[RIDX(js + rr)];
+                                rr += adv; if (rr >= joff) rr -= joff;
+                            }
                         }
                     }
                 }
