@@ -20,11 +20,11 @@ __global__ __launch_bounds__(64) void lzf_xxh32_kernel(const uint8_t* const* __r
     const uint32_t g = (blockIdx.x * 64u + threadIdx.x) >> 2;
     const uint32_t q = threadIdx.x & 3u;
     const bool act = g < n;
-    const uint8_t* p = act ? ptrs[g] : nullptr;
+    cgu8* p = act ? as_global(ptrs[g]) : nullptr;
     const uint64_t len = act ? lens[g] : 0;
     uint32_t v = q == 0 ? XP1 + XP2 : q == 1 ? XP2 : q == 2 ? 0u : 0u - XP1;
     const uint64_t stripes = len >> 4;
-    const uint8_t* sp = p + q * 4u;
+    cgu8* sp = p + q * 4u;
     uint64_t s = 0;
     for (; s + 4 <= stripes; s += 4) {   // 4 loads in flight per lane
         const uint32_t w0 = ld4(sp + (s + 0) * 16), w1 = ld4(sp + (s + 1) * 16);
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(64) void lzf_xxh32_kernel(const uint8_t* const* __r
     if (act && q == 0) {
         if (len < 16) h = XP5;   // seed + PRIME5
         h += (uint32_t)len;
-        const uint8_t* t = p + (stripes << 4);
+        cgu8* t = p + (stripes << 4);
         uint32_t rem = (uint32_t)(len & 15u);
         while (rem >= 4) { h = rotl32(h + ld4(t) * XP3, 17) * XP4; t += 4; rem -= 4; }
         while (rem) { h = rotl32(h + (uint32_t)(*t) * XP5, 11) * XP1; ++t; --rem; }
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void lzf_seed_table_kernel(lzf_u32_table* __re
     const uint64_t count = (dict_len - 8) / 3 + 1;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t o = i * 3;
-        const uint64_t v8 = ld8(dict + o);
+        const uint64_t v8 = ld8(as_global(dict) + o);
         const uint32_t h = (uint32_t)(((v8 << 24) * 889523592379ull) >> 52);
         atomicMax(&t->dict[h], (uint32_t)o);
     }

@@ -56,14 +56,14 @@ constexpr uint32_t kMaxLen = 0x7FFFFF00u;
 
 // Bounded sink with NoPartialWrites semantics (src/framed/compress.rs:294-314).
 struct Sink {
-    uint8_t* out;
+    gu8* out;
     uint32_t pos, cap;
 };
 
 // LSIC tail length in bytes (mod.rs:243-260): 0 if v < 15 else (v-15)/255 + 1.
 __device__ __forceinline__ uint32_t lsic_len(uint32_t v) { return v < 15u ? 0u : (v - 15u) / 255u + 1u; }
 
-__device__ __forceinline__ void lsic_store(uint8_t* dst, uint32_t v, uint32_t n, uint32_t lane) {
+__device__ __forceinline__ void lsic_store(gu8* dst, uint32_t v, uint32_t n, uint32_t lane) {
     // n = lsic_len(v) > 0: n-1 bytes of 0xFF then (v-15) % 255
     for (uint32_t i = lane; i < n; i += kWave) dst[i] = (i + 1u == n) ? (uint8_t)((v - 15u) % 255u) : (uint8_t)0xFF;
 }
@@ -81,19 +81,19 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
     const long long t_start = clock64();
     if (job.table_kind != (uint32_t)KIND) return;   // handled by the other instantiation
 
-    const uint8_t* __restrict__ in = job.input;
+    cgu8* __restrict__ in = as_global(job.input);
     int status = LZF_OK;
-    Sink s{job.out, 0u, job.out_cap > kMaxLen ? kMaxLen : (uint32_t)job.out_cap};
+    Sink s{as_global(job.out), 0u, job.out_cap > kMaxLen ? kMaxLen : (uint32_t)job.out_cap};
     uint64_t base_off = 0;   // EncoderTable.offset (mod.rs:30,:81)
 
     // ---- table in: Default::default() (:32-36) or the caller's table
     if (job.table) {
         if (KIND == LZF_TABLE_U32) {
-            const lzf_u32_table* t = (const lzf_u32_table*)job.table;
+            const LZF_GLOBAL lzf_u32_table* t = (const LZF_GLOBAL lzf_u32_table*)job.table;
             for (uint32_t i = lane; i < TT::kSlots; i += kWave) tab[i] = t->dict[i];
             base_off = t->offset;
         } else {
-            const lzf_u16_table* t = (const lzf_u16_table*)job.table;
+            const LZF_GLOBAL lzf_u16_table* t = (const LZF_GLOBAL lzf_u16_table*)job.table;
             for (uint32_t i = lane; i < TT::kSlots; i += kWave) tab[i] = t->dict[i];
             base_off = t->offset;
         }
@@ -191,7 +191,7 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                     status = LZF_OUTPUT_FULL;
                     break;
                 }
-                uint8_t* d = s.out + s.pos;
+                gu8* d = s.out + s.pos;
                 if (lane == 0) d[0] = (uint8_t)((L < 15u ? L : 15u) << 4);
                 if (nl) lsic_store(d + 1, L, nl, lane);
                 wave_copy(d + 1u + nl, in + ls, L, lane);
@@ -205,8 +205,8 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
             const uint32_t alen = (len - 5u) - m_pos;
             uint32_t m = 4u;   // first 4 bytes already known equal
             {
-                const uint8_t* a = in + m_pos;
-                const uint8_t* b = in + m_cand;
+                cgu8* a = in + m_pos;
+                cgu8* b = in + m_cand;
                 bool done = false;
                 while (!done && alen - m >= 512u) {              // 8 bytes per lane
                     const uint64_t x = ld8(a + m + lane * 8u) ^ ld8(b + m + lane * 8u);
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
             const uint32_t nl = lsic_len(L), ne = lsic_len(extra);
             const uint32_t total = 1u + nl + L + 2u + ne;
             if (s.cap - s.pos < total) { status = LZF_OUTPUT_FULL; break; }
-            uint8_t* d = s.out + s.pos;
+            gu8* d = s.out + s.pos;
             if (lane == 0) {
                 d[0] = (uint8_t)(((L < 15u ? L : 15u) << 4) | (extra < 15u ? extra : 15u));
                 d[1u + nl + L] = (uint8_t)dup_offset;
@@ -279,10 +279,10 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
     // ---- table out (`&mut table`): mutations survive OUTPUT_FULL, like the reference's
     if (job.table && !(job.flags & LZF_CJOB_TABLE_READONLY) && status != LZF_CONTRACT) {
         if (KIND == LZF_TABLE_U32) {
-            lzf_u32_table* t = (lzf_u32_table*)job.table;
+            LZF_GLOBAL lzf_u32_table* t = (LZF_GLOBAL lzf_u32_table*)job.table;
             for (uint32_t i = lane; i < TT::kSlots; i += kWave) t->dict[i] = tab[i];
         } else {
-            lzf_u16_table* t = (lzf_u16_table*)job.table;
+            LZF_GLOBAL lzf_u16_table* t = (LZF_GLOBAL lzf_u16_table*)job.table;
             for (uint32_t i = lane; i < TT::kSlots; i += kWave) t->dict[i] = (uint16_t)tab[i];
         }
     }

@@ -22,7 +22,7 @@ namespace lzf {
 
 // 256-byte register window over the compressed input.
 struct InWindow {
-    const uint8_t* in;
+    cgu8* in;
     uint32_t len;
     uint32_t base;   // wave-uniform; 0xFFFFFFFF = nothing loaded
     uint32_t w;      // lane i: bytes [base+4i, base+4i+4)
@@ -66,9 +66,9 @@ __global__ __launch_bounds__(64) void lzf_decompress_wave_kernel(
     if (job.input_len >= kMaxPos || job.out_existing_len >= kMaxPos || job.prefix_len >= kMaxPos) {
         status = LZF_CONTRACT;   // blocks beyond 2 GiB are outside this kernel's contract
     } else {
-        const uint8_t* __restrict__ in = job.input;
-        const uint8_t* __restrict__ prefix = job.prefix;
-        uint8_t* out = job.out;
+        cgu8* __restrict__ in = as_global(job.input);
+        cgu8* __restrict__ prefix = as_global(job.prefix);
+        gu8* out = as_global(job.out);
         const uint32_t len = (uint32_t)job.input_len;
         const uint32_t plen = (uint32_t)job.prefix_len;
         const uint32_t cap = job.out_cap > kMaxPos ? kMaxPos : (uint32_t)job.out_cap;
@@ -128,8 +128,8 @@ __global__ __launch_bounds__(64) void lzf_decompress_wave_kernel(
             const uint32_t src0 = o - offset;
             const uint32_t span = mlen < offset ? mlen : offset;   // distinct source bytes
             if (src0 + span > safe) { wave_store_fence(); safe = o; }
-            const uint8_t* hist = out + src0;
-            uint8_t* dst = out + o;
+            cgu8* hist = out + src0;
+            gu8* dst = out + o;
             if (mlen <= offset) {
                 wave_copy(dst, hist, mlen, lane);                   // :104-111 non-overlapping
             } else if (offset == 1u) {                              // :102 memset

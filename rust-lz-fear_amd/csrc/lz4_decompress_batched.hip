@@ -65,7 +65,7 @@ __device__ __forceinline__ void put_small_lds(uint32_t dst, uint32_t srca, uint3
     }
 }
 // Same, source in global memory (unaligned loads; reads exactly [g, g+n)).
-__device__ __forceinline__ void put_small_glb(uint32_t dst, const uint8_t* g, uint32_t n) {
+__device__ __forceinline__ void put_small_glb(uint32_t dst, cgu8* g, uint32_t n) {
     if (n >= 8u) {
         const bool big = n > 16u;
         const uint64_t v0 = ld8(g), v3 = ld8(g + n - 8u);
@@ -78,12 +78,15 @@ __device__ __forceinline__ void put_small_glb(uint32_t dst, const uint8_t* g, ui
         const uint32_t v0 = ld4(g), v1 = ld4(g + n - 4u);
         lds_st32(dst, v0); lds_st32(dst + n - 4u, v1);
     } else if (n >= 2u) {
-        const uint32_t v0 = reinterpret_cast<const U2B*>(g)->v, v1 = reinterpret_cast<const U2B*>(g + n - 2u)->v;
+        const uint32_t v0 = ld2(g), v1 = ld2(g + n - 2u);
         lds_st16(dst, v0); lds_st16(dst + n - 2u, v1);
     } else if (n == 1u) {
         lds_st8(dst, g[0]);
     }
 }
+
+struct No { static constexpr bool value = false; };
+struct Yes { static constexpr bool value = true; };
 
 }  // namespace
 
@@ -115,9 +118,9 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
     if (job.input_len >= kMaxPosB || job.out_existing_len >= kMaxPosB || job.prefix_len >= kMaxPosB) {
         status = LZF_CONTRACT;
     } else {
-        const uint8_t* __restrict__ in = job.input;
-        const uint8_t* __restrict__ prefix = job.prefix;
-        uint8_t* out = job.out;
+        cgu8* __restrict__ in = as_global(job.input);
+        cgu8* __restrict__ prefix = as_global(job.prefix);
+        gu8* out = as_global(job.out);
         const uint32_t len = (uint32_t)job.input_len;
         const uint32_t plen = (uint32_t)job.prefix_len;
         const uint32_t cap = job.out_cap > kMaxPosB ? kMaxPosB : (uint32_t)job.out_cap;
@@ -133,7 +136,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
             a += nh;
             const uint32_t nchunks = (b - a) >> 4;
             for (uint32_t c = lane; c < nchunks; c += kWave)
-                *reinterpret_cast<u32x4*>(&ring[RIDX(a + 16u * c)]) = *reinterpret_cast<const u32x4*>(out + a + 16u * c);
+                *reinterpret_cast<u32x4*>(&ring[RIDX(a + 16u * c)]) = *reinterpret_cast<const LZF_GLOBAL u32x4*>(out + a + 16u * c);
             a += nchunks << 4;
             if (lane < b - a) ring[RIDX(a + lane)] = out[a + lane];
         };
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
             a += nh;
             const uint32_t nchunks = (b - a) >> 4;
             for (uint32_t c = lane; c < nchunks; c += kWave)
-                *reinterpret_cast<u32x4*>(out + a + 16u * c) = *reinterpret_cast<const u32x4*>(&ring[RIDX(a + 16u * c)]);
+                *reinterpret_cast<LZF_GLOBAL u32x4*>(out + a + 16u * c) = *reinterpret_cast<const u32x4*>(&ring[RIDX(a + 16u * c)]);
             a += nchunks << 4;
             if (lane < b - a) out[a + lane] = ring[RIDX(a + lane)];
         };
@@ -166,7 +169,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
             // =====================================================================
             {
                 const uint32_t avail = len - cstart < kCB ? len - cstart : kCB;
-                const uint8_t* g = in + cstart;
+                cgu8* g = in + cstart;
 #pragma unroll 1
                 for (uint32_t base = 0; base < kCB; base += 4u * 1024u) {
                     u32x4 v[4];
@@ -185,19 +188,40 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 }
             }
             // byte of the input at absolute position q >= cstart
-            auto rdb = [&](uint32_t q) -> uint32_t { const uint32_t r = q - cstart; return r < kCB ? (uint32_t)cbuf[r] : (uint32_t)in[q]; };
+            // (asm LDS read on purpose: with two plain loads hipcc selects between the pointers and emits
+            //  one FLAT load, which waits on both memory counters at every use)
+            auto rdb = [&](uint32_t q) -> uint32_t {
+                const uint32_t r = q - cstart;
+                if (r < kCB) return lds_ld8(cbuf_a + r);
+                return (uint32_t)in[q];
+            };
             // One token at p (p < len): position of the next token; false on UnexpectedEnd.
             // decompress.rs:61-71 without the copies.
+            uint32_t cutpos_w = 0;     // position of token #TOKCAP when a chunk has more tokens than the list holds
+            // 4 input bytes at q (missing bytes past the end read as 0)
+            auto rd4 = [&](uint32_t q) -> uint32_t {
+                const uint32_t r = q - cstart;
+                if (r + 4u <= kCB) { uint32_t v; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(cbuf_a + r) : "memory"); return v; }
+                uint32_t v = 0;
+                for (uint32_t i = 0; i < 4u && q + i < len; ++i) v |= rdb(q + i) << (8u * i);
+                return v;
+            };
+            // One token at p (p < len): position of the next token; false on UnexpectedEnd.
+            // decompress.rs:61-71 without the copies.  One LDS read covers the token and the first
+            // length-extension byte, which is all a hop needs in the common cases.
             auto token_next = [&](uint32_t p, uint32_t& next) -> bool {
-                const uint32_t tok = rdb(p);
+                const uint32_t w = rd4(p);
+                const uint32_t tok = w & 255u;
                 uint32_t q = p + 1u;
                 uint32_t L = tok >> 4;
                 if (L == 15u) {
-                    for (;;) {
+                    if (q >= len) return false;
+                    uint32_t b = (w >> 8) & 255u; ++q;
+                    L += b;
+                    while (b == 255u) {
                         if (q >= len) return false;
-                        const uint32_t b = rdb(q); ++q;
+                        b = rdb(q); ++q;
                         L += b; if (L > kMaxPosB) L = kMaxPosB;
-                        if (b != 255u) break;
                     }
                 }
                 if (len - q < L) return false;                    // :67 read_exact
@@ -214,6 +238,59 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 next = q;
                 return true;
             };
+            // Walk the token chain from p up to (not including) the first token at or beyond `end`.
+            // Tokens are counted in n and, when RECORD, their positions go to toks[k++].
+            // Divergence control: a lane whose token needs more than the plain 4-byte view (length
+            // extensions, end of input) parks; all other lanes keep hopping with one LDS read and a
+            // handful of VALU per hop, and parked lanes are served together by the general routine.
+            auto walk = [&](uint32_t p, const uint32_t end, uint32_t& n, uint32_t& k, bool& err, auto RECORD) -> uint32_t {
+                const uint32_t fast_end = len > 24u ? len - 24u : 0u;     // plain hops stay clear of the input's end
+                bool parked = false;
+                for (;;) {
+                    for (;;) {
+                        const bool active = !parked && p < end && p < len;
+                        if (!__any(active)) break;
+                        if (active) {
+                            // plain view of the token: 4 bytes at p cover the token and its first literal-length
+                            // extension byte; a match-length extension byte costs one more read.  Anything
+                            // beyond that (0xFF runs, bodies leaving the staged bytes, the input's end) parks.
+                            bool simple = false;
+                            if (p < fast_end) {
+                                uint32_t w;
+                                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(cbuf_a + (p - cstart)) : "memory");
+                                uint32_t L = (w >> 4) & 15u;
+                                const uint32_t Mn = w & 15u, b1 = (w >> 8) & 255u;
+                                const bool ext = L == 15u;
+                                if (ext) L += b1;
+                                uint32_t q = p + 3u + (ext ? 1u : 0u) + L;          // first byte after the offset
+                                bool ok = !(ext && b1 == 255u) && q < fast_end && (q - cstart) < kCB;
+                                if (ok && Mn == 15u) {
+                                    const uint32_t m1 = lds_ld8(cbuf_a + (q - cstart));
+                                    ok = m1 != 255u;
+                                    ++q;
+                                }
+                                if (ok) {
+                                    simple = true;
+                                    if (RECORD.value) { if (k < (uint32_t)TOKCAP) toks[k] = (uint16_t)(p - cstart); else if (k == (uint32_t)TOKCAP) cutpos_w = p; ++k; }
+                                    ++n; p = q;
+                                }
+                            }
+                            if (!simple) parked = true;
+                        }
+                    }
+                    if (!__any(parked)) break;
+                    if (parked) {
+                        uint32_t nx;
+                        if (!token_next(p, nx)) { err = true; p = len; }
+                        else {
+                            if (RECORD.value) { if (k < (uint32_t)TOKCAP) toks[k] = (uint16_t)(p - cstart); else if (k == (uint32_t)TOKCAP) cutpos_w = p; ++k; }
+                            ++n; p = nx;
+                        }
+                        parked = false;
+                    }
+                }
+                return p;
+            };
             // =====================================================================
             // A. speculative lane-parallel parse of one chunk: regions [cstart + i*S, +S)
             // =====================================================================
@@ -222,25 +299,15 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
             // First guess: walk in from the previous region's start (for lane 1 that is a true token),
             // so that the chain has usually re-synchronised by the time it enters the lane's region.
             uint32_t start = lane == 0 ? cstart : rbeg - (uint32_t)S;
-            uint32_t x = 0, n = 0;
+            uint32_t x = 0, n = 0, kdummy = 0;
             bool lerr = false;
+            {
+                uint32_t nw = 0; bool ew = false;
+                start = walk(start, rbeg, nw, kdummy, ew, No{});      // warm-up: these tokens do not count
+            }
             for (uint32_t pass = 0; pass < 70u; ++pass) {
-                uint32_t p = start;
-                if (pass == 0u) {                                  // warm-up: tokens before the region do not count
-                    while (p < rbeg && p < len) {
-                        uint32_t nx;
-                        if (!token_next(p, nx)) { p = len; break; }
-                        p = nx;
-                    }
-                    start = p;
-                }
                 n = 0; lerr = false;
-                while (p < rend && p < len) {
-                    uint32_t nx;
-                    if (!token_next(p, nx)) { lerr = true; p = len; break; }
-                    ++n; p = nx;
-                }
-                x = p;
+                x = walk(start, rend, n, kdummy, lerr, No{});
                 // true exits never decrease along the stream, so a lane starts at the largest exit
                 // before it (a long literal run hands its exit to every region it skips at once)
                 const uint32_t nstart = wave_prev(wave_scan_max(x), cstart);
@@ -253,21 +320,14 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
             const uint32_t T = __builtin_amdgcn_readlane(incl_n, 63);
             const bool cut = T > (uint32_t)TOKCAP;
             const uint32_t Tc = cut ? (uint32_t)TOKCAP : T;
-            uint32_t cutpos = 0;
             {   // record pass
-                uint32_t p = start, k = rank0;
-                while (p < rend && p < len) {
-                    uint32_t nx;
-                    if (!token_next(p, nx)) break;
-                    if (k < (uint32_t)TOKCAP) toks[k] = (uint16_t)(p - cstart);
-                    else if (k == (uint32_t)TOKCAP) cutpos = p;
-                    ++k; p = nx;
-                }
+                uint32_t k = rank0, n2 = 0; bool e2 = false;
+                (void)walk(start, rend, n2, k, e2, Yes{});
             }
             uint32_t cend;        // where the next chunk starts
             int cerr = LZF_OK;    // UnexpectedEnd right after the listed tokens
             if (cut) {
-                cend = __builtin_amdgcn_readlane(cutpos, first_lane(__ballot(rank0 <= (uint32_t)TOKCAP && rank0 + n > (uint32_t)TOKCAP)) & 63u);
+                cend = __builtin_amdgcn_readlane(cutpos_w, first_lane(__ballot(rank0 <= (uint32_t)TOKCAP && rank0 + n > (uint32_t)TOKCAP)) & 63u);
             } else {
                 cend = __builtin_amdgcn_readlane(x, 63);
                 if (__ballot(lerr)) cerr = LZF_UNEXPECTED_END;
@@ -339,8 +399,8 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                             const uint32_t src0 = o - offset;
                             const uint32_t span = mlen < offset ? mlen : offset;
                             if (src0 + span > safe) { wave_store_fence(); safe = o; }
-                            const uint8_t* hist = out + src0;
-                            uint8_t* dst = out + o;
+                            cgu8* hist = out + src0;
+                            gu8* dst = out + o;
                             if (mlen <= offset) {
                                 wave_copy(dst, hist, mlen, lane);
                             } else if (offset == 1u) {

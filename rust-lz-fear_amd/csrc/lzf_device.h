@@ -17,10 +17,21 @@ struct __attribute__((packed, aligned(1))) U8B { uint64_t v; };
 struct __attribute__((packed, aligned(1))) U4B { uint32_t v; };
 struct __attribute__((packed, aligned(1))) U2B { uint16_t v; };
 
-__device__ __forceinline__ u32x4 ld16(const uint8_t* p) { return reinterpret_cast<const U16B*>(p)->v; }
-__device__ __forceinline__ void st16(uint8_t* p, u32x4 v) { reinterpret_cast<U16B*>(p)->v = v; }
-__device__ __forceinline__ uint64_t ld8(const uint8_t* p) { return reinterpret_cast<const U8B*>(p)->v; }
-__device__ __forceinline__ uint32_t ld4(const uint8_t* p) { return reinterpret_cast<const U4B*>(p)->v; }
+// Job pointers arrive inside a struct, so hipcc only knows them as generic pointers and would emit
+// FLAT loads/stores (which count against both vmcnt and lgkmcnt and are slower).  Everything a
+// job points at lives in HBM: the kernels cast to the global address space once, and every helper
+// below takes global pointers, so the accesses compile to global_load / global_store.
+#define LZF_GLOBAL __attribute__((address_space(1)))
+typedef LZF_GLOBAL uint8_t gu8;
+typedef const LZF_GLOBAL uint8_t cgu8;
+template <typename T> __device__ __forceinline__ cgu8* as_global(const T* p) { return (cgu8*)p; }
+template <typename T> __device__ __forceinline__ gu8* as_global(T* p) { return (gu8*)p; }
+
+__device__ __forceinline__ u32x4 ld16(cgu8* p) { return reinterpret_cast<const LZF_GLOBAL U16B*>(p)->v; }
+__device__ __forceinline__ void st16(gu8* p, u32x4 v) { reinterpret_cast<LZF_GLOBAL U16B*>(p)->v = v; }
+__device__ __forceinline__ uint64_t ld8(cgu8* p) { return reinterpret_cast<const LZF_GLOBAL U8B*>(p)->v; }
+__device__ __forceinline__ uint32_t ld4(cgu8* p) { return reinterpret_cast<const LZF_GLOBAL U4B*>(p)->v; }
+__device__ __forceinline__ uint32_t ld2(cgu8* p) { return reinterpret_cast<const LZF_GLOBAL U2B*>(p)->v; }
 
 __device__ __forceinline__ uint32_t rfl(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -38,7 +49,7 @@ __device__ __forceinline__ void wave_store_fence() {
 
 // Cooperative forward copy of n bytes, source and destination not overlapping *within the
 // copied range* (the source is fully written before the call).  All 64 lanes participate.
-__device__ __forceinline__ void wave_copy(uint8_t* __restrict__ dst, const uint8_t* __restrict__ src,
+__device__ __forceinline__ void wave_copy(gu8* __restrict__ dst, cgu8* __restrict__ src,
                                           uint32_t n, uint32_t lane) {
     if (n <= kWave) {
         if (lane < n) dst[lane] = src[lane];
