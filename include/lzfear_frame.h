@@ -1,0 +1,107 @@
+/*
+ * lzfear_frame.h — C ABI of the host-side LZ4 *frame* layer that drives the GPU block codec
+ * (SURVEY.md §8 row f1).  It mirrors lz-fear's `framed` module:
+ *
+ *   CompressionSettings + compress / compress_with_size   src/framed/compress.rs:36-157
+ *   compress_internal (header, block loop, EndMark)       src/framed/compress.rs:160-282
+ *   LZ4FrameReader::new / decode_block / decompress_frame src/framed/decompress.rs:102-288
+ *   Flags / BlockDescriptor                               src/framed/header.rs:8-81
+ *   MAGIC / INCOMPRESSIBLE / WINDOW_SIZE                  src/framed/mod.rs:16-20
+ *
+ * The reference calls the block codec once per block (compress.rs:243, decompress.rs:248); here
+ * all independent blocks of a frame go to the GPU in ONE batch (lzf_compress_batch /
+ * lzf_decompress_batch of lzfear_hip.h); linked-block frames are inherently sequential and run
+ * block after block with the table / window carried between calls.
+ * Buffers are host memory.  No CPU codec: the calls fail with LZF_E_NO_DEVICE without a GPU.
+ */
+#ifndef LZFEAR_FRAME_H
+#define LZFEAR_FRAME_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "lzfear_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* frame-level status codes (>= 16; block-level DecodeError codes 1..4 of lzfear_hip.h pass through
+ * as `CodecError`, src/framed/decompress.rs:20-21) */
+enum {
+    LZF_F_INPUT_ERROR = 16,            /* DecompressionError::InputError (EOF), decompress.rs:18-19 */
+    LZF_F_WRONG_MAGIC = 17,            /* :24-25 */
+    LZF_F_HEADER_CHECKSUM_FAIL = 18,   /* :26-27 */
+    LZF_F_BLOCK_CHECKSUM_FAIL = 19,    /* :28-29 */
+    LZF_F_FRAME_CHECKSUM_FAIL = 20,    /* :30-31 */
+    LZF_F_BLOCK_LENGTH_OVERFLOW = 21,  /* :32-33 */
+    LZF_F_BLOCK_SIZE_OVERFLOW = 22,    /* :34-35 */
+    LZF_F_UNIMPLEMENTED_BLOCKSIZE = 23,/* header::ParseError, header.rs:19-28 */
+    LZF_F_UNSUPPORTED_VERSION = 24,
+    LZF_F_RESERVED_FLAG_BITS = 25,
+    LZF_F_RESERVED_BD_BITS = 26,
+    LZF_F_INVALID_BLOCK_SIZE = 27,     /* CompressionError::InvalidBlockSize, compress.rs:21-22 */
+    LZF_F_PANIC = 28                   /* BlockDescriptor::new unwrap() panic, header.rs:55 */
+};
+
+#define LZF_MAGIC 0x184D2204u          /* src/framed/mod.rs:16 */
+#define LZF_WINDOW_SIZE 65536u         /* src/framed/mod.rs:20 */
+
+/* CompressionSettings (src/framed/compress.rs:36-55) plus the `content_size: Option<u64>` of
+ * compress_internal (:160; compress_with_size passes Some(len), :148-157). */
+typedef struct lzf_settings {
+    int32_t independent_blocks;     /* default 1  (:47) */
+    int32_t block_checksums;        /* default 0  (:48) */
+    int32_t content_checksum;       /* default 1  (:49) */
+    int32_t has_dictionary_id;      /* dictionary(id, d) sets it; dictionary_id_nonsense_override clears/sets it (:113-133) */
+    uint64_t block_size;            /* default 4 MiB (:50); 64 KiB / 256 KiB / 1 MiB / 4 MiB */
+    const uint8_t* dictionary;      /* NULL = None (:51) */
+    uint64_t dictionary_len;
+    uint32_t dictionary_id;
+    int32_t has_content_size;
+    uint64_t content_size;
+} lzf_settings;
+
+void lzf_settings_default(lzf_settings* s);                       /* Default::default(), :44-55 */
+size_t lzf_frame_compress_bound(const lzf_settings* s, size_t in_len);
+
+/* CompressionSettings::compress / compress_with_size_unchecked over memory buffers.
+ * Returns LZF_OK, LZF_F_INVALID_BLOCK_SIZE, LZF_F_PANIC, LZF_OUT_CAPACITY or a negative LZF_E_*. */
+int lzf_frame_compress(const lzf_settings* s, const uint8_t* in, size_t in_len,
+                       uint8_t* out, size_t out_cap, size_t* out_len);
+
+/* Parsed frame header (LZ4FrameReader::new + accessors :167-175). */
+typedef struct lzf_frame_info {
+    uint8_t flags;                  /* FLG byte */
+    uint8_t bd;                     /* BD byte */
+    uint16_t header_len;            /* bytes up to and including HC */
+    uint32_t dictionary_id;
+    int32_t has_dictionary_id;
+    int32_t has_content_size;
+    uint64_t content_size;
+    uint64_t block_maxsize;
+} lzf_frame_info;
+int lzf_frame_read_header(const uint8_t* in, size_t in_len, lzf_frame_info* info);
+
+/* decompress_frame (:284-288) with an optional dictionary (into_read_with_dictionary, :180).
+ * Status is the inner error kind (what decode_block returns).  *out_len = bytes produced by the
+ * blocks completed before the error; *consumed = bytes of `in` read. */
+int lzf_frame_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, size_t dict_len,
+                         uint8_t* out, size_t out_cap, size_t* out_len, size_t* consumed);
+
+/* XXH32 on the host (header / content checksums; twox-hash XxHash32 in the reference). */
+uint32_t lzf_xxh32(const uint8_t* p, size_t len, uint32_t seed);
+
+/* Frame assembly from already-compressed blocks (what rank 0 does after the RCCL all-gather of a
+ * block-sharded compression): writes header, then for every block
+ * [u32 len | stored-bit][bytes][xxh32]?, then EndMark and content checksum.
+ *   comp_len[i] == UINT32_MAX  => block i is stored raw (compress2 returned LZF_OUTPUT_FULL)
+ *   payload[i] points at comp_len[i] compressed bytes, or at the raw block when stored.
+ * `raw_len[i]` is the uncompressed length of block i. */
+int lzf_frame_assemble(const lzf_settings* s, uint32_t n_blocks, const uint8_t* const* payload,
+                       const uint32_t* comp_len, const uint32_t* raw_len, uint32_t content_xxh32,
+                       uint8_t* out, size_t out_cap, size_t* out_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LZFEAR_FRAME_H */

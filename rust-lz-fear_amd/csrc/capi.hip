@@ -46,6 +46,8 @@ int decompress_variant() {
         if (!strcmp(e, "wave")) return 0;
         if (!strcmp(e, "batched8")) return 8;
         if (!strcmp(e, "batched8s")) return 32;
+        if (!strcmp(e, "batched4")) return 4;
+        if (!strcmp(e, "batched4s")) return 5;
         return 16;
     }();
     return v;
@@ -94,6 +96,8 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
     switch (decompress_variant()) {
         case 0: hipLaunchKernelGGL(lzf::lzf_decompress_wave_kernel, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
         case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<8192, 128, 1024>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
+        case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<4096, 128, 1024>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
+        case 5: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<4096, 64, 512>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
         case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<8192, 64, 512>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
         default: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<16384, 128, 1024>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
     }

@@ -11,6 +11,8 @@ __global__ void lzf_decompress_batched_kernel(const lzf_decompress_job* __restri
 extern template __global__ void lzf_decompress_batched_kernel<16384, 128, 1024>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
 extern template __global__ void lzf_decompress_batched_kernel<8192, 128, 1024>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
 extern template __global__ void lzf_decompress_batched_kernel<8192, 64, 512>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+extern template __global__ void lzf_decompress_batched_kernel<4096, 128, 1024>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+extern template __global__ void lzf_decompress_batched_kernel<4096, 64, 512>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
 template <int KIND>
 __global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
                                          lzf_job_result* __restrict__ results, uint32_t n_jobs);

@@ -630,5 +630,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
 template __global__ void lzf_decompress_batched_kernel<16384, 128, 1024>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
 template __global__ void lzf_decompress_batched_kernel<8192, 128, 1024>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
 template __global__ void lzf_decompress_batched_kernel<8192, 64, 512>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+template __global__ void lzf_decompress_batched_kernel<4096, 128, 1024>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+template __global__ void lzf_decompress_batched_kernel<4096, 64, 512>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
 
 }  // namespace lzf

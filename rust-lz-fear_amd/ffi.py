@@ -50,10 +50,28 @@ class JobResult(C.Structure):
 
 assert C.sizeof(CompressJob) == 56 and C.sizeof(DecompressJob) == 64 and C.sizeof(JobResult) == 16
 
+class Settings(C.Structure):
+    """lzf_settings — CompressionSettings, src/framed/compress.rs:36-55"""
+    _fields_ = [("independent_blocks", C.c_int32), ("block_checksums", C.c_int32), ("content_checksum", C.c_int32),
+                ("has_dictionary_id", C.c_int32), ("block_size", C.c_uint64), ("dictionary", C.c_void_p),
+                ("dictionary_len", C.c_uint64), ("dictionary_id", C.c_uint32), ("has_content_size", C.c_int32),
+                ("content_size", C.c_uint64)]
+
+
+class FrameInfo(C.Structure):
+    _fields_ = [("flags", C.c_uint8), ("bd", C.c_uint8), ("header_len", C.c_uint16), ("dictionary_id", C.c_uint32),
+                ("has_dictionary_id", C.c_int32), ("has_content_size", C.c_int32), ("content_size", C.c_uint64),
+                ("block_maxsize", C.c_uint64)]
+
+
 EXPORTS = [
     "lzf_abi_version", "lzf_last_error", "lzf_device_count", "lzf_compress_batch",
     "lzf_decompress_batch", "lzf_table_seed_from_dictionary", "lzf_table_offset",
     "lzf_xxh32_batch", "lzf_compress_batch_host", "lzf_decompress_batch_host",
+]
+FRAME_EXPORTS = [
+    "lzf_settings_default", "lzf_frame_compress_bound", "lzf_frame_compress", "lzf_frame_read_header",
+    "lzf_frame_decompress", "lzf_xxh32", "lzf_frame_assemble",
 ]
 
 _lib = None
@@ -86,6 +104,17 @@ def lib():
         L.lzf_xxh32_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.lzf_compress_batch_host.argtypes = [C.POINTER(CompressJob), C.POINTER(JobResult), C.c_uint32]
         L.lzf_decompress_batch_host.argtypes = [C.POINTER(DecompressJob), C.POINTER(JobResult), C.c_uint32]
+        L.lzf_settings_default.argtypes = [C.POINTER(Settings)]
+        L.lzf_frame_compress_bound.restype = C.c_size_t
+        L.lzf_frame_compress_bound.argtypes = [C.POINTER(Settings), C.c_size_t]
+        L.lzf_frame_compress.argtypes = [C.POINTER(Settings), C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.lzf_frame_read_header.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(FrameInfo)]
+        L.lzf_frame_decompress.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                           C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.lzf_xxh32.restype = C.c_uint32
+        L.lzf_xxh32.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
+        L.lzf_frame_assemble.argtypes = [C.POINTER(Settings), C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
+                                         C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _lib = L
     return _lib
 

@@ -18,8 +18,8 @@ def lib():
     return ffi.lib()
 
 
-def declared_functions():
-    hdr = open(os.path.join(ROOT, "include", "lzfear_hip.h")).read()
+def declared_functions(name="lzfear_hip.h"):
+    hdr = open(os.path.join(ROOT, "include", name)).read()
     hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
     return sorted(set(re.findall(r"\b(lzf_[a-z0-9_]+)\s*\(", hdr)))
 
@@ -31,9 +31,29 @@ def test_header_declares_expected_entry_points():
 
 
 def test_library_exports_every_declared_symbol(lib):
-    for name in declared_functions():
+    for name in declared_functions() + declared_functions("lzfear_frame.h"):
         assert hasattr(lib, name), name
     assert lib.lzf_abi_version() == 1
+    assert sorted(declared_functions("lzfear_frame.h")) == sorted(ffi.FRAME_EXPORTS)
+
+
+def test_frame_layer_host_only_pieces(lib):
+    """Header parsing, XXH32 and frame assembly are pure host code: usable without a GPU."""
+    import ctypes as C
+    import xxhash
+    for n in (0, 1, 15, 16, 17, 1000):
+        d = bytes(range(256)) * 4
+        assert lib.lzf_xxh32(d[:n], n, 0) == xxhash.xxh32(d[:n]).intdigest()
+    s = ffi.Settings()
+    lib.lzf_settings_default(C.byref(s))
+    assert (s.independent_blocks, s.block_checksums, s.content_checksum, s.block_size) == (1, 0, 1, 4 << 20)
+    hc = (xxhash.xxh32(bytes([0x64, 0x70])).intdigest() >> 8) & 0xFF
+    frame = bytes.fromhex("04224d186470") + bytes([hc]) + bytes(4) + (0x02CC5D05).to_bytes(4, "little")   # empty default frame
+    info = ffi.FrameInfo()
+    assert lib.lzf_frame_read_header(frame, len(frame), C.byref(info)) == 0
+    assert info.block_maxsize == 4 << 20 and info.header_len == 7
+    assert lib.lzf_frame_read_header(b"\x00" * 7, 7, C.byref(info)) == 17          # WrongMagic
+    assert lib.lzf_frame_read_header(frame[:5], 5, C.byref(info)) == 16             # InputError
 
 
 def test_struct_layouts_match_header():

@@ -1,0 +1,166 @@
+"""GPU tests (-m gpu) of the frame layer (include/lzfear_frame.h) — lz-fear's `framed` module with
+every block coded by the HIP kernels — against the oracle's frame restatement: exact frame bytes
+over the flag matrix of tests/output_equivalence.rs, the issue-15 regression, the survey
+fingerprints, dictionary modes, and malformed frames with pinned error kinds."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_ffi as o
+import vectors
+import rust_lz_fear_amd  # noqa: F401
+from rust_lz_fear_amd import framed, synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+fp = lambda b: [len(b), "%08x" % o.xxh32(b)]
+
+
+def settings_pair(**kw):
+    """(GPU-side CompressionSettings, oracle settings) from the same keyword set."""
+    g = framed.CompressionSettings()
+    if "independent_blocks" in kw: g.independent_blocks(kw["independent_blocks"])
+    if "block_checksums" in kw: g.block_checksums(kw["block_checksums"])
+    if "content_checksum" in kw: g.content_checksum(kw["content_checksum"])
+    if "block_size" in kw: g.block_size(kw["block_size"])
+    if "dictionary" in kw:
+        g.dictionary(kw.get("dictionary_id", 0), kw["dictionary"])
+        if kw.get("dictionary_id") is None:
+            g.dictionary_id_nonsense_override(None)
+    okw = {k: v for k, v in kw.items()}
+    return g, okw
+
+
+@pytest.mark.parametrize("bits", range(32))
+def test_flag_matrix_exact_frame_bytes(bits):
+    """tests/output_equivalence.rs:58-101 flag matrix (bit 2 = block size, run here at 64/256 KiB)."""
+    data = synth.silesia_mix(0, 700_000).tobytes()
+    kw = dict(content_checksum=not (bits & 1), independent_blocks=not (bits & 2),
+              block_size=(256 << 10) if bits & 4 else (64 << 10))
+    if bits & 8:
+        kw["dictionary"] = bytes([1, 3, 3, 7]); kw["dictionary_id"] = None
+    g, okw = settings_pair(**kw)
+    size = len(data) if bits & 16 else None
+    got = g.compress_with_size(data) if size is not None else g.compress(data)
+    rc, want = o.frame_compress(data, o.make_settings(content_size=size, **okw))
+    assert rc == 0 and got == want
+    assert framed.decompress_frame(got, dictionary=kw.get("dictionary", b"")) == data
+
+
+def test_default_settings_4mib_blocks():
+    data = synth.silesia_mix(5 << 20, 15 << 20).tobytes()          # 2.5 blocks of 4 MiB
+    got = framed.CompressionSettings().compress(data)
+    rc, want = o.frame_compress(data)
+    assert rc == 0 and got == want
+    assert framed.decompress_frame(got) == data
+
+
+def test_survey_frame_fingerprints():
+    S = json.load(open(os.path.join(GOLD, "survey_fingerprints.json")))
+    g3 = synth.lcg_bytes(5, 262144, 3)
+    assert fp(framed.CompressionSettings().block_size(65536).compress(g3)) == S["G3"]["frame_64k_independent"]
+    f = framed.CompressionSettings().block_size(65536).independent_blocks(False).block_checksums(True).compress_with_size(g3)
+    assert fp(f) == S["G3"]["frame_64k_linked_blocksum_csize"]
+    assert framed.decompress_frame(f) == g3
+    kb = synth.lcg_bytes(3, 69632, 3)
+    f = framed.CompressionSettings().block_size(65536).independent_blocks(False).compress(kb)
+    assert fp(f) == S["KAT-B"]["frame_64k_linked"]                  # quirks B1/B3 through the GPU table carry
+    assert framed.decompress_frame(f) == kb
+
+
+def test_issue15_regression_linked_64k():
+    data = open(os.path.join(GOLD, "issue15_input.bin"), "rb").read()
+    f = framed.CompressionSettings().independent_blocks(False).block_size(64 * 1024).compress(data)   # tests/issue-15.rs:10-13
+    assert len(f) == 81160
+    assert f == o.frame_compress(data, o.make_settings(independent_blocks=False, block_size=64 * 1024))[1]
+    assert framed.decompress_frame(f) == data                       # :15-21
+
+
+def test_corpus_frame_and_checksum_failure():
+    data = open(os.path.join(GOLD, "uncomp.data.lz4"), "rb").read()
+    J = json.load(open(os.path.join(GOLD, "corpus_frames.json")))["valid_frames"]["uncomp.data.lz4"]
+    assert fp(framed.decompress_frame(data)) == [J["out_len"], J["out_xxh32"]]
+    bad = bytearray(data); bad[20] ^= 1
+    with pytest.raises(framed.FrameError) as e:
+        framed.decompress_frame(bytes(bad))
+    assert e.value.code == o.F_FRAME_CHECKSUM_FAIL
+    info = framed.read_header(data)
+    assert info.block_maxsize == 64 << 10 and info.flags == 0x64 and info.bd == 0x40
+
+
+def test_dictionary_modes():
+    d = synth.gen_text_zipf(3, 70000).tobytes()
+    data = synth.gen_text_zipf(4, 300000).tobytes()
+    for indep in (True, False):
+        g = framed.CompressionSettings().independent_blocks(indep).block_size(64 << 10).dictionary(42, d)
+        f = g.compress(data)
+        rc, want = o.frame_compress(data, o.make_settings(independent_blocks=indep, block_size=64 << 10, dictionary=d, dictionary_id=42))
+        assert rc == 0 and f == want
+        assert framed.decompress_frame(f, dictionary=d) == data
+        assert framed.read_header(f).dictionary_id == 42
+        with pytest.raises(framed.FrameError):
+            framed.decompress_frame(f)                               # missing dictionary
+
+
+def test_block_size_validation():
+    for bs in (1, 1000, 32 << 10, 2 << 20, 8 << 20):
+        with pytest.raises(framed.FrameError) as e:
+            framed.CompressionSettings().block_size(bs).compress(b"x")
+        assert e.value.code == o.F_INVALID_BLOCK_SIZE
+    for bs in (0, 16 << 20):
+        with pytest.raises(framed.FrameError) as e:
+            framed.CompressionSettings().block_size(bs).compress(b"x")
+        assert e.value.code == o.F_PANIC
+
+
+def test_incompressible_and_empty():
+    data = vectors.rng_bytes(5, 200000)
+    f = framed.CompressionSettings().block_size(64 << 10).compress(data)
+    assert f == o.frame_compress(data, o.make_settings(block_size=64 << 10))[1]
+    assert framed.decompress_frame(f) == data
+    e = framed.CompressionSettings().compress(b"")
+    assert e == o.frame_compress(b"")[1] and framed.decompress_frame(e) == b""
+
+
+def mutate(rng, frame):
+    b = bytearray(frame)
+    kind = rng.integers(0, 5)
+    if kind == 0 and len(b) > 8:
+        del b[rng.integers(7, len(b)):]
+    elif kind == 1:
+        i = rng.integers(0, len(b)); b[i] ^= 1 << rng.integers(0, 8)
+    elif kind == 2:
+        i = rng.integers(4, min(len(b), 12)); b[i] = rng.integers(0, 256)       # header bytes
+    elif kind == 3:
+        i = rng.integers(0, len(b)); b[i] = 0 if rng.integers(0, 2) else 0xFF
+    else:
+        for _ in range(3):
+            i = rng.integers(0, len(b)); b[i] = rng.integers(0, 256)
+    return bytes(b)
+
+
+def test_malformed_frames_same_error_kind_and_partial_output():
+    """fuzz/fuzz_targets/decode.rs idea with pinned kinds: every mutated frame must fail (or
+    succeed) exactly like the reference restatement, block by block."""
+    rng = np.random.default_rng(777)
+    base = []
+    data = synth.silesia_mix(40 << 20, (40 << 20) + 300_000).tobytes()
+    for kw in (dict(block_size=64 << 10), dict(block_size=64 << 10, independent_blocks=False),
+               dict(block_size=64 << 10, block_checksums=True), dict(block_size=256 << 10, content_checksum=False)):
+        base.append(o.frame_compress(data, o.make_settings(**kw))[1])
+    base.append(o.frame_compress(vectors.rng_bytes(2, 100000), o.make_settings(block_size=64 << 10))[1])
+    kinds = set()
+    for f in base:
+        for _ in range(40):
+            m = mutate(rng, f)
+            erc, eout, _ = o.frame_decompress(m, cap=16 << 20)
+            try:
+                out = framed.decompress_frame(m, cap=16 << 20); rc = 0
+            except framed.FrameError as e:
+                rc, out = e.code, e.partial
+            assert rc == erc, (rc, erc, len(m))
+            assert out == eout
+            kinds.add(rc)
+    assert len(kinds) >= 8, kinds
