@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--copies", type=int, default=20, help="tiled copies of silesia_mix per GPU (51 blocks each)")
+    ap.add_argument("--copies", type=int, default=120, help="tiled copies of silesia_mix per GPU (51 blocks each)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -194,6 +194,14 @@ def main():
     total_bytes = float(tot[0])
 
     d_bytes = float(lens[kidx].sum() + clen[kidx].sum())               # C + N of the kernel's jobs
+    # HBM traffic from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950
+    # correction + WRITE_SIZE), scaled from the profiled launch to this launch by job count
+    d_traffic = c_traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if os.path.exists(tpath):
+        tj = json.load(open(tpath))
+        d_traffic = (2 * tj["decompress"]["FETCH_SIZE_KB"] + tj["decompress"]["WRITE_SIZE_KB"]) * 1024.0 * nk / tj["decompress"]["jobs"]
+        c_traffic = (2 * tj["compress"]["FETCH_SIZE_KB"] + tj["compress"]["WRITE_SIZE_KB"]) * 1024.0 * nblk / tj["compress"]["jobs"]
     d_achieved = d_bytes / (d_kernel_ms * 1e-3) / 1e9
     c_achieved = c_bytes / (c_kernel_ms * 1e-3) / 1e9
 
@@ -216,15 +224,15 @@ def main():
                                    (copies, float(lens.sum()) / float(clen.sum() + lens[stored_idx].sum())),
                        "blocks_per_gpu": int(nblk), "stored_blocks_per_gpu": int(len(stored_idx)),
                        "block_size": BS, "parallelism": f"block-sharded x{world}, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "lzf_decompress_wave_kernel",
+            "roofline": {"bound": "hbm", "kernel": "lzf_decompress_batched_kernel<4096,128,1024>",
                          "achieved": round(d_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(d_achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "frac": round(d_achieved / HBM_PEAK_GBS, 5), "traffic": d_traffic,
                          "algorithmic_bytes_per_launch": d_bytes, "kernel_ms": round(d_kernel_ms, 4)},
             "compress": {"value": round(total_bytes * c_steps / tc_max / 2**30, 3), "unit": "GiB/s (uncompressed bytes compressed per second)",
                          "steps": c_steps, "ms_per_step": round(tc_max / c_steps * 1e3, 3),
                          "roofline": {"bound": "hbm", "kernel": "lzf_compress_wave_kernel<U32>",
                                       "achieved": round(c_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": round(c_achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                                      "frac": round(c_achieved / HBM_PEAK_GBS, 5), "traffic": c_traffic,
                                       "algorithmic_bytes_per_launch": c_bytes, "kernel_ms": round(c_kernel_ms, 3)}},
             "cpu_baseline": cpu,
         }

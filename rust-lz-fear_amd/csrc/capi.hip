@@ -38,17 +38,18 @@ int ensure_device() {
 
 // Kernel generation used by lzf_decompress_batch.  Tuning / A-B knob only (both generations
 // implement the same contract): LZF_DECOMPRESS_KERNEL = wave | batched16 (ring 16K, regions 128 B) | batched8 (8K, 128) |
-// batched8s (8K, 64).
+// batched8s (8K, 64) | batched4 (4K, 128; the default) | batched4s (4K, 64).
 int decompress_variant() {
     static const int v = [] {
         const char* e = getenv("LZF_DECOMPRESS_KERNEL");
-        if (!e || !*e) return 16;
+        if (!e || !*e) return 4;
         if (!strcmp(e, "wave")) return 0;
         if (!strcmp(e, "batched8")) return 8;
         if (!strcmp(e, "batched8s")) return 32;
         if (!strcmp(e, "batched4")) return 4;
         if (!strcmp(e, "batched4s")) return 5;
-        return 16;
+        if (!strcmp(e, "batched16")) return 16;
+        return 4;
     }();
     return v;
 }

@@ -144,6 +144,17 @@ def test_decompress_overlap_offsets():
         assert e[0] == 0 and r == e
 
 
+@pytest.mark.parametrize("variant", ["wave", "batched4", "batched4s", "batched8", "batched8s", "batched16"])
+def test_every_decompress_kernel_generation(variant):
+    """Both kernel generations (and every ring/region geometry) implement the same contract."""
+    import subprocess, sys
+    env = dict(os.environ, LZF_DECOMPRESS_KERNEL=variant)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "variant_check.py")], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "variant ok" in r.stdout
+
+
 # ---------------------------------------------------------------- compress
 def test_compress_u32_bit_exact():
     cases = all_cases()
