@@ -109,22 +109,44 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
         uint32_t cursor = init;
         const uint32_t boff = (uint32_t)base_off;   // low 32 bits; overflow is checked at commit
 
+        // 8 input bytes at pos; bytes at or beyond len read as 0
+        auto ld8_part = [&](uint32_t pos) -> uint64_t {
+            if (pos + 8u <= len) return ld8(in + pos);
+            uint64_t v = 0;
+            for (uint32_t i = 0; pos + i < len; ++i) v |= (uint64_t)in[pos + i] << (8u * i);
+            return v;
+        };
+        // The first batch of a literal run probes cursor + lane; those 16 bytes per lane are requested
+        // as soon as the cursor is known (before the previous sequence is emitted) and consumed here.
+        uint32_t pf_c = 0xFFFFFFFFu;
+        uint64_t pfA0 = 0, pfA1 = 0;
+
         while (cursor < len && status == LZF_OK) {                        // :171
             const uint32_t ls = cursor;                                   // :172 literal_start
             uint32_t n = 0;          // probe index inside this literal run
             uint32_t c = cursor;     // position of probe n
             bool finished = false;   // last-literals path taken
-            uint32_t m_pos = 0, m_cand = 0;   // winner
+            uint32_t m_pos = 0, m_cand = 0, m = 4u, bt = 0;
+            bool more_m = false, more_bt = false;
+            uint64_t wA0 = 0, wA1 = 0;        // the winner's 16 input bytes
 
             // ================= search: speculative batches of the :177-232 loop
             for (;;) {
-                const uint32_t sn = sched_prefix(n);
-                const uint32_t ck = c + (sched_prefix(n + lane) - sn);
+                // probe positions: the first 66 probes of a run advance by 1 (mod.rs:225-231)
+                uint32_t ck, sn = 0;
+                if (n + 64u <= 66u) ck = c + lane;
+                else { sn = sched_prefix(n); ck = c + (sched_prefix(n + lane) - sn); }
                 const bool endk = (ck > len) || (len - ck < 12u);         // :178
                 const bool active = !endk;
-                uint64_t v8 = 0;
-                if (active) v8 = ld8(in + ck);       // >= 12 bytes remain: the 8-byte read is in range
-                const uint32_t h = TT::hash(v8);
+                uint64_t A0 = 0, A1 = 0;                                  // input[ck .. ck+16)
+#ifdef LZF_C_NOPF
+                if (false) {}
+#else
+                if (n == 0u && pf_c == c) { A0 = pfA0; A1 = pfA1; }
+#endif
+                else if (active) { A0 = ld8(in + ck); A1 = ld8_part(ck + 8u); }   // >= 12 bytes remain
+                pf_c = 0xFFFFFFFFu;
+                const uint32_t h = TT::hash(A0);
                 uint32_t old = 0, first = lane;
                 if (active) old = tab[h];
                 if (active) tab[h] = kMark;
@@ -138,12 +160,32 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                 {
                     const uint64_t stored = old;
                     cand = stored > base_off ? (uint32_t)(stored - base_off) : 0u;   // :70 saturating_sub
-                    const uint32_t c_first = __shfl(ck, (int)(first & 63u));
-                    if (lane == D) cand = c_first;
+                    if (D < 64u) {
+                        const uint32_t fD = __builtin_amdgcn_readlane(first, D);
+                        const uint32_t c_first = __builtin_amdgcn_readlane(ck, fD & 63u);
+                        if (lane == D) cand = c_first;
+                    }
                 }
-                bool valid = false;
-                if (active && lane <= D && ck != init && cand <= ck && ck - cand <= 0xFFFFu) {   // :200-201
-                    valid = ld4(in + cand) == (uint32_t)v8;               // :204-206 (m >= 4)
+                // candidate side, one round trip: 16 bytes at the candidate for the >= 4 test and the
+                // forward extension, 8 bytes before both positions for the backtrack
+                const bool reach = active && lane <= D && ck != init && cand <= ck && ck - cand <= 0xFFFFu;   // :200-201
+                uint64_t B0 = 0, B1 = 0, PA = 0, PB = 0;
+                const bool btfast = cand >= 8u;        // (then ck >= 8 as well)
+                if (reach) {
+                    B0 = ld8(in + cand); B1 = ld8_part(cand + 8u);
+                    if (btfast) { PA = ld8(in + ck - 8u); PB = ld8(in + cand - 8u); }
+                }
+                const bool valid = reach && (uint32_t)A0 == (uint32_t)B0;  // :204-206 (m >= 4)
+                uint32_t m_loc = 0, bt_loc = 0, maxbt = 0;
+                if (valid) {
+                    const uint64_t x0 = A0 ^ B0, x1 = A1 ^ B1;
+                    m_loc = x0 ? (uint32_t)(__builtin_ctzll(x0) >> 3) : 8u + (x1 ? (uint32_t)(__builtin_ctzll(x1) >> 3) : 8u);
+                    const uint32_t runlen = ck - (ls + (n == 0u ? 0u : 0u));
+                    maxbt = runlen < cand ? runlen : cand;                 // :211-212 bounds
+                    if (btfast) {
+                        const uint64_t xp = PA ^ PB;
+                        bt_loc = xp ? (uint32_t)(__builtin_clzll(xp) >> 3) : 8u;
+                    }
                 }
                 const uint32_t W = first_lane(__ballot(valid));
                 // last lane whose `replace` really executed in sequential order (+1)
@@ -162,7 +204,7 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                 if (active) {
                     if (lane < commit_end) {
                         // lane first[D] is overridden by D when D commits
-                        const uint32_t fD = __shfl(first, (int)(D & 63u));
+                        const uint32_t fD = D < 64u ? __builtin_amdgcn_readlane(first, D & 63u) : 64u;
                         const bool overridden = (D < commit_end) && (lane == fD) && (lane != D);
                         if (!overridden) tab[h] = ck + boff;
                     } else if (first >= commit_end) {
@@ -171,13 +213,25 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                 }
                 if (status != LZF_OK) break;
                 if (outcome == 1) {
-                    m_pos = __shfl(ck, (int)W);
-                    m_cand = __shfl(cand, (int)W);
+                    m_pos = __builtin_amdgcn_readlane(ck, W);
+                    m_cand = __builtin_amdgcn_readlane(cand, W);
+                    const uint32_t alen_w = (len - 5u) - m_pos;            // :195
+                    const uint32_t mw = __builtin_amdgcn_readlane(m_loc, W);
+                    m = mw < alen_w ? mw : alen_w;
+                    more_m = mw >= 16u && alen_w > 16u;
+                    const uint32_t mbw = __builtin_amdgcn_readlane(maxbt, W);
+                    const uint32_t btw = __builtin_amdgcn_readlane(bt_loc, W);
+                    const bool fastw = m_cand >= 8u;
+                    bt = fastw ? (btw < mbw ? btw : mbw) : 0u;
+                    more_bt = fastw ? (btw >= 8u && mbw > 8u) : (mbw > 0u);
+                    wA0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(A0 >> 32), W) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)A0, W);
+                    wA1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(A1 >> 32), W) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)A1, W);
                     break;
                 }
                 if (outcome == 2) { finished = true; break; }
                 n += commit_end;
-                c += sched_prefix(n) - sn;
+                if (n <= 66u) c += commit_end;
+                else c += sched_prefix(n) - (sn ? sn : sched_prefix(n - commit_end));
             }
             if (status != LZF_OK) break;
 
@@ -201,10 +255,9 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
             }
 
             // ================= match found at m_pos against m_cand (distance checked)
-            // forward extension: common prefix of input[m_pos .. len-5) and input[m_cand ..) (:195,:203-204)
+            // forward extension beyond the 16 bytes compared in registers (:195,:203-204)
             const uint32_t alen = (len - 5u) - m_pos;
-            uint32_t m = 4u;   // first 4 bytes already known equal
-            {
+            if (more_m) {
                 cgu8* a = in + m_pos;
                 cgu8* b = in + m_cand;
                 bool done = false;
@@ -213,7 +266,8 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                     const unsigned long long neq = __ballot(x != 0ull);
                     if (neq) {
                         const uint32_t fl = (uint32_t)__builtin_ctzll(neq);
-                        const uint64_t xf = __shfl(x, (int)fl);
+                        const uint32_t xlo = __builtin_amdgcn_readlane((uint32_t)x, fl), xhi = __builtin_amdgcn_readlane((uint32_t)(x >> 32), fl);
+                        const uint64_t xf = ((uint64_t)xhi << 32) | xlo;
                         m += fl * 8u + (uint32_t)(__builtin_ctzll(xf) >> 3);
                         done = true;
                     } else {
@@ -230,11 +284,10 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                     else m += 64u;
                 }
             }
-            // backtrack (:211-212): at most (m_pos - ls) and at most m_cand bytes
-            uint32_t bt = 0;
-            {
+            // backtrack beyond the 8 bytes compared in registers (:211-212)
+            if (more_bt) {
                 const uint32_t maxbt = (m_pos - ls) < m_cand ? (m_pos - ls) : m_cand;
-                bool done = maxbt == 0u;
+                bool done = false;
                 while (!done) {
                     const uint32_t i = bt + lane;
                     bool ne = true;
@@ -244,19 +297,38 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                     else bt += 64u;
                 }
             }
-            const uint32_t dup_offset = m_pos - m_cand;                    // :208
-            const uint32_t extra = m - 4u + bt;                            // :206,:214
             cursor = m_pos + m;                                            // :215
+            // request the next run's first probes now; they land while this sequence is emitted
+            {
+                const uint32_t ckn = cursor + lane;
+                pfA0 = 0; pfA1 = 0;
+                if (ckn <= len && len - ckn >= 12u) { pfA0 = ld8(in + ckn); pfA1 = ld8_part(ckn + 8u); }
+                pf_c = cursor;
+            }
             // table.replace(input, cursor - 2) — unconditional (:218, quirks B1/B3)
             {
                 const uint32_t q = cursor - 2u;
                 if ((uint64_t)q + base_off > TT::kLimit) { status = LZF_CONTRACT; break; }
                 uint64_t v8 = 0;
-                if (KIND == LZF_TABLE_U32) { if (len - q >= 8u) v8 = ld8(in + q); }   // :43 else 0
-                else v8 = ld4(in + q);                                                // >= 7 bytes remain
+                const uint32_t need = KIND == LZF_TABLE_U32 ? 8u : 4u;
+                if (KIND != LZF_TABLE_U32 || len - q >= 8u) {              // :43: fewer than 8 bytes left -> 0
+#ifdef LZF_C_NOREG
+                    if (false) {
+#else
+                    if (m - 2u + need <= 16u) {                            // still inside the winner's 16 bytes
+#endif
+                        const uint32_t sh = (m - 2u) * 8u;
+                        v8 = sh == 0u ? wA0 : sh < 64u ? ((wA0 >> sh) | (wA1 << (64u - sh))) : (wA1 >> (sh - 64u));
+                        if (KIND != LZF_TABLE_U32) v8 &= 0xFFFFFFFFull;
+                    } else {
+                        v8 = KIND == LZF_TABLE_U32 ? ld8(in + q) : (uint64_t)ld4(in + q);
+                    }
+                }
                 const uint32_t h = TT::hash(v8);
                 if (lane == 0) tab[h] = q + boff;
             }
+            const uint32_t dup_offset = m_pos - m_cand;                    // :208
+            const uint32_t extra = m - 4u + bt;                            // :206,:214
             // ================= write_group, mod.rs:150-163 (+ :235 literal slice)
             const uint32_t lit_end = cursor - extra - 4u;
             const uint32_t L = lit_end - ls;
