@@ -155,6 +155,30 @@ def test_every_decompress_kernel_generation(variant):
     assert "variant ok" in r.stdout
 
 
+def test_decompress_handcrafted_streams():
+    """Blocks assembled sequence by sequence (tests/vectors.py synth_stream): shapes a greedy
+    compressor never emits — > 1024 tokens per 8 KiB (token-list cut), multi-KiB literal runs and
+    matches (solo path, cooperative paths), 90 000-byte overlapping matches, offsets 1..8 and
+    near 65 535 — must decode like the reference restatement, at every output-limit outcome."""
+    cases = []
+    for seed, n, prof in [(1, 6000, "dense"), (2, 3000, "mixed"), (3, 400, "long"), (4, 2000, "rle"),
+                          (5, 20000, "mixed"), (6, 150, "long"), (7, 9000, "dense"), (8, 5000, "rle")]:
+        cases.append(vectors.synth_stream(seed, n, prof))
+    items = []
+    for blk, out in cases:
+        items.append(dict(input=blk, limit=len(out), out_cap=len(out) + len(blk) + 64))
+        items.append(dict(input=blk, limit=len(out) // 2, out_cap=len(out) + len(blk) + 64))     # MemoryLimitExceeded somewhere
+        items.append(dict(input=blk[: len(blk) * 2 // 3], limit=len(out), out_cap=len(out) + len(blk) + 64))   # truncated
+    res = gpu_decompress(items)
+    for it, (rc, got) in zip(items, res):
+        erc, eout = o.decompress_raw(it["input"], limit=it["limit"], cap=it["out_cap"])
+        assert rc == erc
+        if rc == 0:
+            assert got == eout
+    for (blk, out), (rc, got) in zip(cases, res[::3]):
+        assert rc == 0 and got == out
+
+
 # ---------------------------------------------------------------- compress
 def test_compress_u32_bit_exact():
     cases = all_cases()

@@ -48,6 +48,11 @@ def main():
     comp = o.compress2(dic + payload, cursor=len(dic))[1]
     r = ffi.decompress_blocks_host([dict(input=comp, prefix=dic, limit=len(payload)), dict(input=comp, existing=dic, limit=len(d))])
     assert r[0] == (0, payload) and r[1] == (0, d)
+    # handcrafted streams (rare kernel paths)
+    for seed, n, prof in [(11, 4000, "dense"), (12, 2000, "mixed"), (13, 200, "long"), (14, 1500, "rle")]:
+        blk, out = vectors.synth_stream(seed, n, prof)
+        (rc, got), = ffi.decompress_blocks_host([dict(input=blk, limit=len(out), out_cap=len(out) + len(blk) + 64)])
+        assert rc == 0 and got == out, (prof, rc)
     print("variant ok:", os.environ.get("LZF_DECOMPRESS_KERNEL", "(default)"), len(cases), "blocks,", len(items), "malformed")
 
 

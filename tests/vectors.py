@@ -67,3 +67,55 @@ def medium_cases():
     cases.append(("lcg3_mask3_69632", synth.lcg_bytes(3, 69632, 3)))
     cases.append(("mixed_1m", synth.silesia_mix(9 << 20, 10 << 20).tobytes()))
     return cases
+
+
+def lsic(v):
+    """LSIC tail bytes of a length whose nibble already holds min(v, 15) (mod.rs:243-260)."""
+    if v < 15:
+        return b""
+    v -= 15
+    return b"\xff" * (v // 255) + bytes([v % 255])
+
+
+def synth_stream(seed, n_seq, profile):
+    """A VALID raw LZ4 block built sequence by sequence (not by a compressor), so that shapes no
+    greedy parse would emit are covered: dense 3-byte tokens, huge literal runs and matches,
+    offsets 1..8, offsets near 64 KiB, prefix-free.  Returns (block bytes, decoded bytes)."""
+    rng = np.random.default_rng(seed)
+    out = bytearray()
+    blk = bytearray()
+    for i in range(n_seq):
+        r = rng.random()
+        if profile == "dense":            # tokens every 3 bytes: no literals, 4-byte matches
+            L = 0 if i else 8
+            M = 4 + int(rng.integers(0, 3))
+        elif profile == "mixed":
+            L = int(rng.integers(0, 20)) if r < 0.9 else int(rng.integers(20, 400))
+            M = 4 + (int(rng.integers(0, 24)) if r < 0.85 else int(rng.integers(24, 700)))
+        elif profile == "long":
+            L = int(rng.integers(0, 6000)) if r < 0.3 else int(rng.integers(0, 40))
+            M = 4 + (int(rng.integers(0, 90000)) if r > 0.8 else int(rng.integers(0, 60)))
+        else:                             # "rle": tiny offsets, overlapping copies
+            L = int(rng.integers(0, 5))
+            M = 4 + int(rng.integers(0, 300))
+        if len(out) + L == 0:
+            L = 4
+        lit = bytes(rng.integers(0, 256, L, dtype=np.uint8))
+        avail = len(out) + L
+        if profile == "rle" or rng.random() < 0.15:
+            off = int(rng.integers(1, min(avail, 9) + 1)) if avail >= 1 else 1
+        elif rng.random() < 0.1:
+            off = min(avail, 65535 - int(rng.integers(0, 50)))
+        else:
+            off = int(rng.integers(1, min(avail, 65535) + 1))
+        off = max(1, min(off, avail, 65535))
+        blk += bytes([(min(L, 15) << 4) | min(M - 4, 15)]) + lsic(L) + lit + off.to_bytes(2, "little") + lsic(M - 4)
+        out += lit
+        start = len(out) - off
+        for k in range(M):
+            out.append(out[start + k])
+    # last literals
+    tail = bytes(rng.integers(0, 256, 7, dtype=np.uint8))
+    blk += bytes([len(tail) << 4]) + tail
+    out += tail
+    return bytes(blk), bytes(out)
