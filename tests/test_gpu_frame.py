@@ -164,3 +164,58 @@ def test_malformed_frames_same_error_kind_and_partial_output():
             assert out == eout
             kinds.add(rc)
     assert len(kinds) >= 8, kinds
+
+
+# ---------------------------------------------------------------- BASELINE.json configs as parity cases
+def test_config1_text_64k_default_frame():
+    """configs[0]: one 64 KiB block of enwik8-like text, default CompressionSettings."""
+    data = synth.text_zipf_64k().tobytes()
+    f = framed.CompressionSettings().compress(data)
+    assert f == o.frame_compress(data)[1]
+    assert framed.read_header(f).block_maxsize == 4 << 20
+    assert framed.decompress_frame(f) == data
+
+
+def test_config4_log_text_blocks_and_sharded_assembly():
+    """configs[3] in miniature: log-text stream, 4 MiB independent blocks; the frame assembled from
+    block-sharded GPU output (what the RCCL all-gather reassembles) equals the single-call frame."""
+    import ctypes as C
+    from rust_lz_fear_amd import ffi
+    bs = 4 << 20
+    data = synth.log_text(3 * bs, 3 * bs + 2 * bs + 777_777).tobytes()
+    whole = framed.CompressionSettings().compress(data)
+    assert whole == o.frame_compress(data)[1]
+    nblk = (len(data) + bs - 1) // bs
+    blocks = [data[i * bs:(i + 1) * bs] for i in range(nblk)]
+    res = ffi.compress_blocks_host([dict(input=b, out_cap=len(b)) for b in blocks])      # "rank-local" batches
+    payload = [c if rc == 0 else b for (rc, c), b in zip(res, blocks)]
+    bufs = [C.create_string_buffer(p, max(len(p), 1)) for p in payload]
+    ptrs = (C.c_void_p * nblk)(*[C.cast(b, C.c_void_p) for b in bufs])
+    cl = (C.c_uint32 * nblk)(*[len(c) if rc == 0 else 0xFFFFFFFF for rc, c in res])
+    rl = (C.c_uint32 * nblk)(*[len(b) for b in blocks])
+    s = framed.CompressionSettings()._struct(None)
+    out = C.create_string_buffer(len(data) + 1024)
+    n = C.c_size_t(0)
+    assert ffi.lib().lzf_frame_assemble(C.byref(s), nblk, ptrs, cl, rl, ffi.lib().lzf_xxh32(data, len(data), 0), out, len(out), C.byref(n)) == 0
+    assert out.raw[: n.value] == whole
+    assert framed.decompress_frame(whole) == data
+
+
+def test_config5_repeat256_linked_dictionary_and_u16():
+    """configs[4]: 256-byte motif; (5a) framed 64 KiB linked blocks with a 64 KiB dictionary of the
+    same motif (the U32Table linked path, the only one the reference's frame layer has);
+    (5b) raw compress2::<U16Table> on 65 535-byte slices, cursor 0 and behind a 4096-byte prefix."""
+    from rust_lz_fear_amd import ffi
+    motif_dict = synth.repeat256(65536).tobytes()
+    data = synth.repeat256(5 * 65536 + 1234).tobytes()
+    g = framed.CompressionSettings().independent_blocks(False).block_size(64 << 10).dictionary(7, motif_dict)
+    f = g.compress(data)
+    rc, want = o.frame_compress(data, o.make_settings(independent_blocks=False, block_size=64 << 10, dictionary=motif_dict, dictionary_id=7))
+    assert rc == 0 and f == want and len(f) < 3000
+    assert framed.decompress_frame(f, dictionary=motif_dict) == data
+    sl = synth.repeat256(65535).tobytes()
+    res = ffi.compress_blocks_host([dict(input=sl, kind=ffi.TABLE_U16), dict(input=sl, cursor=4096, kind=ffi.TABLE_U16)])
+    assert res[0] == o.compress2(sl, kind=o.TABLE_U16)
+    assert res[1] == o.compress2(sl, cursor=4096, kind=o.TABLE_U16)
+    back = ffi.decompress_blocks_host([dict(input=res[0][1], limit=65535), dict(input=res[1][1], prefix=sl[:4096], limit=65535 - 4096)])
+    assert back[0] == (0, sl) and back[1] == (0, sl[4096:])
