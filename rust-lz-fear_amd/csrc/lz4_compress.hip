@@ -53,6 +53,7 @@ template <> struct TableTraits<LZF_TABLE_U16> {
 
 constexpr uint32_t kMark = 0xFFFFFFFFu;
 constexpr uint32_t kMaxLen = 0x7FFFFF00u;
+constexpr uint32_t kFirstBatch = 16;     // lanes probing in the first batch of a literal run
 
 // Bounded sink with NoPartialWrites semantics (src/framed/compress.rs:294-314).
 struct Sink {
@@ -83,6 +84,9 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
 
     cgu8* __restrict__ in = as_global(job.input);
     int status = LZF_OK;
+#ifdef LZF_PHASE_TIMING
+    long long g_tph[4] = {0, 0, 0, 0};
+#endif
     Sink s{as_global(job.out), 0u, job.out_cap > kMaxLen ? kMaxLen : (uint32_t)job.out_cap};
     uint64_t base_off = 0;   // EncoderTable.offset (mod.rs:30,:81)
 
@@ -120,6 +124,12 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
         // as soon as the cursor is known (before the previous sequence is emitted) and consumed here.
         uint32_t pf_c = 0xFFFFFFFFu;
         uint64_t pfA0 = 0, pfA1 = 0;
+#ifdef LZF_PHASE_TIMING
+        long long tq = clock64();
+#define CPHASE(i) do { const long long tn = clock64(); g_tph[i] += tn - tq; tq = tn; } while (0)
+#else
+#define CPHASE(i) do { } while (0)
+#endif
 
         while (cursor < len && status == LZF_OK) {                        // :171
             const uint32_t ls = cursor;                                   // :172 literal_start
@@ -136,14 +146,15 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                 uint32_t ck, sn = 0;
                 if (n + 64u <= 66u) ck = c + lane;
                 else { sn = sched_prefix(n); ck = c + (sched_prefix(n + lane) - sn); }
-                const bool endk = (ck > len) || (len - ck < 12u);         // :178
-                const bool active = !endk;
+                // A run's first batch is narrow: on compressible data the match is almost always among the
+                // first probes, and 16 scattered table/candidate accesses cost far less than 64 (LDS bank
+                // conflicts, one cache line per lane); the batch widens once the run has missed 16 times.
+                const uint32_t bw = n == 0u ? kFirstBatch : kWave;
+                const bool inb = lane < bw;
+                const bool endk = inb && ((ck > len) || (len - ck < 12u));   // :178
+                const bool active = inb && !endk;
                 uint64_t A0 = 0, A1 = 0;                                  // input[ck .. ck+16)
-#ifdef LZF_C_NOPF
-                if (false) {}
-#else
                 if (n == 0u && pf_c == c) { A0 = pfA0; A1 = pfA1; }
-#endif
                 else if (active) { A0 = ld8(in + ck); A1 = ld8_part(ck + 8u); }   // >= 12 bytes remain
                 pf_c = 0xFFFFFFFFu;
                 const uint32_t h = TT::hash(A0);
@@ -180,7 +191,7 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                 if (valid) {
                     const uint64_t x0 = A0 ^ B0, x1 = A1 ^ B1;
                     m_loc = x0 ? (uint32_t)(__builtin_ctzll(x0) >> 3) : 8u + (x1 ? (uint32_t)(__builtin_ctzll(x1) >> 3) : 8u);
-                    const uint32_t runlen = ck - (ls + (n == 0u ? 0u : 0u));
+                    const uint32_t runlen = ck - ls;
                     maxbt = runlen < cand ? runlen : cand;                 // :211-212 bounds
                     if (btfast) {
                         const uint64_t xp = PA ^ PB;
@@ -194,7 +205,7 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                 if (W < e_end && W <= D) { commit_end = W + 1u; outcome = 1; }
                 else if (D < 64u) { commit_end = D + 1u; outcome = 0; }
                 else if (e_end < 64u) { commit_end = e_end; outcome = 2; }
-                else { commit_end = 64u; outcome = 0; }
+                else { commit_end = bw; outcome = 0; }
                 // EncoderTable contract (:67/:92): position + offset must fit the slot type
                 {
                     const bool bad = active && lane < commit_end && ((uint64_t)ck + base_off > TT::kLimit);
@@ -234,6 +245,7 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                 else c += sched_prefix(n) - (sn ? sn : sched_prefix(n - commit_end));
             }
             if (status != LZF_OK) break;
+            CPHASE(0);
 
             if (finished) {
                 // ---- last literals, mod.rs:178-190
@@ -298,11 +310,12 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                 }
             }
             cursor = m_pos + m;                                            // :215
+            CPHASE(1);
             // request the next run's first probes now; they land while this sequence is emitted
             {
                 const uint32_t ckn = cursor + lane;
                 pfA0 = 0; pfA1 = 0;
-                if (ckn <= len && len - ckn >= 12u) { pfA0 = ld8(in + ckn); pfA1 = ld8_part(ckn + 8u); }
+                if (lane < kFirstBatch && ckn <= len && len - ckn >= 12u) { pfA0 = ld8(in + ckn); pfA1 = ld8_part(ckn + 8u); }
                 pf_c = cursor;
             }
             // table.replace(input, cursor - 2) — unconditional (:218, quirks B1/B3)
@@ -312,11 +325,7 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                 uint64_t v8 = 0;
                 const uint32_t need = KIND == LZF_TABLE_U32 ? 8u : 4u;
                 if (KIND != LZF_TABLE_U32 || len - q >= 8u) {              // :43: fewer than 8 bytes left -> 0
-#ifdef LZF_C_NOREG
-                    if (false) {
-#else
                     if (m - 2u + need <= 16u) {                            // still inside the winner's 16 bytes
-#endif
                         const uint32_t sh = (m - 2u) * 8u;
                         v8 = sh == 0u ? wA0 : sh < 64u ? ((wA0 >> sh) | (wA1 << (64u - sh))) : (wA1 >> (sh - 64u));
                         if (KIND != LZF_TABLE_U32) v8 &= 0xFFFFFFFFull;
@@ -329,6 +338,7 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
             }
             const uint32_t dup_offset = m_pos - m_cand;                    // :208
             const uint32_t extra = m - 4u + bt;                            // :206,:214
+            CPHASE(2);
             // ================= write_group, mod.rs:150-163 (+ :235 literal slice)
             const uint32_t lit_end = cursor - extra - 4u;
             const uint32_t L = lit_end - ls;
@@ -345,6 +355,7 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
             wave_copy(d + 1u + nl, in + ls, L, lane);
             if (ne) lsic_store(d + 3u + nl + L, extra, ne, lane);
             s.pos += total;
+            CPHASE(3);
         }
     }
 
@@ -361,7 +372,11 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
     if (lane == 0) {
         results[jid].out_len = s.pos;
         results[jid].status = status;
+#ifdef LZF_PHASE_TIMING
+        { uint32_t pk = 0; for (int i = 0; i < 4; ++i) { uint32_t u = (uint32_t)(g_tph[i] >> 23); if (u > 255u) u = 255u; pk |= u << (8 * i); } results[jid].reserved = pk; }
+#else
         results[jid].reserved = (uint32_t)((clock64() - t_start) >> 10);   // diagnostic: shader kilo-cycles spent on this job
+#endif
     }
 }
 

@@ -57,6 +57,8 @@ for i in range(n):
     cl=int(res['out_len'][i]) if res['status'][i]==0 else 0
     ns = nseq(comp[i*BS:i*BS+cl].tolist()) if (cl and i%4==0) else -1
     if PH:
+        cp = int(res['reserved'][i]); cph = [((cp >> (8*k)) & 255) * 8.4 for k in range(4)]
+        print(f"{i:3d} {seg(i):9s} compress phases(Mcyc) search={cph[0]:.0f} extend={cph[1]:.0f} insert/prefetch={cph[2]:.0f} emit={cph[3]:.0f}")
         pk = (int(r2['out_len'][i]) >> 32) | (int(r2['reserved'][i]) << 32)
         ph = [(pk >> (10*k)) & 1023 for k in range(6)]
         print(f"{i:3d} {seg(i):9s} {cl:8d} phases(Mcyc) parse={ph[0]} setup/err={ph[1]} lit={ph[2]} far={ph[3]} rounds={ph[4]} flush={ph[5]} nseq={ns}")
