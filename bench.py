@@ -54,7 +54,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--copies", type=int, default=120, help="tiled copies of silesia_mix per GPU (51 blocks each)")
+    ap.add_argument("--copies", type=int, default=240, help="tiled copies of silesia_mix per GPU (51 blocks each)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
@@ -224,7 +224,7 @@ def main():
                                    (copies, float(lens.sum()) / float(clen.sum() + lens[stored_idx].sum())),
                        "blocks_per_gpu": int(nblk), "stored_blocks_per_gpu": int(len(stored_idx)),
                        "block_size": BS, "parallelism": f"block-sharded x{world}, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "lzf_decompress_batched_kernel<4096,128,1024>",
+            "roofline": {"bound": "hbm", "kernel": "lzf_decompress_batched_kernel<4096,256,2048,direct>",
                          "achieved": round(d_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(d_achieved / HBM_PEAK_GBS, 5), "traffic": d_traffic,
                          "algorithmic_bytes_per_launch": d_bytes, "kernel_ms": round(d_kernel_ms, 4)},

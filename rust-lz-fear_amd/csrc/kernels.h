@@ -5,14 +5,22 @@
 namespace lzf {
 __global__ void lzf_decompress_wave_kernel(const lzf_decompress_job* __restrict__ jobs,
                                            lzf_job_result* __restrict__ results, uint32_t n_jobs);
-template <int RING, int S, int TOKCAP>
+template <int RING, int S, int TOKCAP, bool STAGE>
 __global__ void lzf_decompress_batched_kernel(const lzf_decompress_job* __restrict__ jobs,
                                               lzf_job_result* __restrict__ results, uint32_t n_jobs);
-extern template __global__ void lzf_decompress_batched_kernel<16384, 128, 1024>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
-extern template __global__ void lzf_decompress_batched_kernel<8192, 128, 1024>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
-extern template __global__ void lzf_decompress_batched_kernel<8192, 64, 512>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
-extern template __global__ void lzf_decompress_batched_kernel<4096, 128, 1024>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
-extern template __global__ void lzf_decompress_batched_kernel<4096, 64, 512>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+#define LZF_EXT(R, S_, T, ST) extern template __global__ void lzf_decompress_batched_kernel<R, S_, T, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t)
+LZF_EXT(16384, 128, 1024, true);
+LZF_EXT(8192, 128, 1024, true);
+LZF_EXT(8192, 64, 512, true);
+LZF_EXT(4096, 128, 1024, true);
+LZF_EXT(4096, 64, 512, true);
+LZF_EXT(4096, 128, 1024, false);
+LZF_EXT(4096, 256, 2048, false);
+LZF_EXT(8192, 256, 2048, false);
+LZF_EXT(4096, 128, 512, false);
+LZF_EXT(2048, 128, 512, false);
+LZF_EXT(4096, 64, 512, false);
+LZF_EXT(2048, 128, 1024, false);
 template <int KIND>
 __global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
                                          lzf_job_result* __restrict__ results, uint32_t n_jobs);

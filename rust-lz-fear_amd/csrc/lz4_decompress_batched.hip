@@ -90,18 +90,19 @@ struct Yes { static constexpr bool value = true; };
 
 }  // namespace
 
-template <int RING, int S, int TOKCAP>
+template <int RING, int S, int TOKCAP, bool STAGE>
 __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
     const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs) {
     constexpr uint32_t kMask = RING - 1;
     constexpr uint32_t kSpanMax = RING / 4;            // output bytes one batch may produce
     constexpr uint32_t kNearHist = RING - kSpanMax;    // history before the batch that stays intact in the ring
     constexpr uint32_t kChunk = 64u * S;               // compressed bytes whose tokens one parse covers
-    constexpr uint32_t kCB = kChunk + 64u;             // staged bytes: the chunk + room for token bodies
+    constexpr uint32_t kCB = STAGE ? kChunk + 64u : 0u;   // staged bytes: the chunk + room for token bodies (0: read HBM/L2 directly)
     static_assert(kChunk <= 65536, "token positions are stored as u16 offsets into the chunk");
     static_assert(kCB % 16 == 0, "chunk buffer is filled in 16-byte pieces");
+    constexpr uint32_t kCBAlloc = STAGE ? kCB : 16u;
     __shared__ __attribute__((aligned(16))) uint8_t ring[RING];
-    __shared__ __attribute__((aligned(16))) uint8_t cbuf[kCB];
+    __shared__ __attribute__((aligned(16))) uint8_t cbuf[kCBAlloc];
     __shared__ uint16_t toks[TOKCAP];
 
     const uint32_t jid = blockIdx.x;
@@ -167,7 +168,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
             // =====================================================================
             // A0. stage in[cstart, cstart + kCB) in LDS
             // =====================================================================
-            {
+            if (STAGE) {
                 const uint32_t avail = len - cstart < kCB ? len - cstart : kCB;
                 cgu8* g = in + cstart;
 #pragma unroll 1
@@ -201,7 +202,8 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
             // 4 input bytes at q (missing bytes past the end read as 0)
             auto rd4 = [&](uint32_t q) -> uint32_t {
                 const uint32_t r = q - cstart;
-                if (r + 4u <= kCB) { uint32_t v; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(cbuf_a + r) : "memory"); return v; }
+                if (!STAGE) { if (q + 4u <= len) return ld4(in + q); }
+                else if (r + 4u <= kCB) { uint32_t v; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(cbuf_a + r) : "memory"); return v; }
                 uint32_t v = 0;
                 for (uint32_t i = 0; i < 4u && q + i < len; ++i) v |= rdb(q + i) << (8u * i);
                 return v;
@@ -257,15 +259,16 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                             bool simple = false;
                             if (p < fast_end) {
                                 uint32_t w;
-                                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(cbuf_a + (p - cstart)) : "memory");
+                                if (STAGE) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(cbuf_a + (p - cstart)) : "memory");
+                                else w = ld4(in + p);
                                 uint32_t L = (w >> 4) & 15u;
                                 const uint32_t Mn = w & 15u, b1 = (w >> 8) & 255u;
                                 const bool ext = L == 15u;
                                 if (ext) L += b1;
                                 uint32_t q = p + 3u + (ext ? 1u : 0u) + L;          // first byte after the offset
-                                bool ok = !(ext && b1 == 255u) && q < fast_end && (q - cstart) < kCB;
+                                bool ok = !(ext && b1 == 255u) && q < fast_end && (!STAGE || (q - cstart) < kCB);
                                 if (ok && Mn == 15u) {
-                                    const uint32_t m1 = lds_ld8(cbuf_a + (q - cstart));
+                                    const uint32_t m1 = STAGE ? lds_ld8(cbuf_a + (q - cstart)) : (uint32_t)in[q];
                                     ok = m1 != 255u;
                                     ++q;
                                 }
@@ -453,7 +456,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                     if (n1 > 0u) {
                         if (ri + n1 > (uint32_t)RING) {                     // wraps around the ring: bytes
                             for (uint32_t t = 0; t < n1; ++t) ring[RIDX(lo + t)] = (uint8_t)rdb(src + t);
-                        } else if (src - cstart + n1 <= kCB) {
+                        } else if (STAGE && src - cstart + n1 <= kCB) {
                             put_small_lds(ring_a + ri, cbuf_a + (src - cstart), n1);
                         } else {
                             put_small_glb(ring_a + ri, in + src, n1);
@@ -627,10 +630,18 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
     }
 }
 
-template __global__ void lzf_decompress_batched_kernel<16384, 128, 1024>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
-template __global__ void lzf_decompress_batched_kernel<8192, 128, 1024>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
-template __global__ void lzf_decompress_batched_kernel<8192, 64, 512>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
-template __global__ void lzf_decompress_batched_kernel<4096, 128, 1024>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
-template __global__ void lzf_decompress_batched_kernel<4096, 64, 512>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+#define LZF_INST(R, S_, T, ST) template __global__ void lzf_decompress_batched_kernel<R, S_, T, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t)
+LZF_INST(16384, 128, 1024, true);
+LZF_INST(8192, 128, 1024, true);
+LZF_INST(8192, 64, 512, true);
+LZF_INST(4096, 128, 1024, true);
+LZF_INST(4096, 64, 512, true);
+LZF_INST(4096, 128, 1024, false);
+LZF_INST(4096, 256, 2048, false);
+LZF_INST(8192, 256, 2048, false);
+LZF_INST(4096, 128, 512, false);
+LZF_INST(2048, 128, 512, false);
+LZF_INST(4096, 64, 512, false);
+LZF_INST(2048, 128, 1024, false);
 
 }  // namespace lzf
