@@ -142,6 +142,11 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
 
             // ================= search: speculative batches of the :177-232 loop
             for (;;) {
+                // Common case, decided once per batch with scalar compares: first batch of a run, not at
+                // the block's edges.  Then every lane is a plain probe (no schedule arithmetic, no end-of-
+                // input lanes, full 16-byte loads in range, positions fit the slot type).
+                const bool easy = n == 0u && c > init && c >= 8u && (uint64_t)c + kFirstBatch + 40u <= len &&
+                                  (uint64_t)c + kFirstBatch + base_off <= TT::kLimit;
                 // probe positions: the first 66 probes of a run advance by 1 (mod.rs:225-231)
                 uint32_t ck, sn = 0;
                 if (n + 64u <= 66u) ck = c + lane;
@@ -151,10 +156,11 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                 // conflicts, one cache line per lane); the batch widens once the run has missed 16 times.
                 const uint32_t bw = n == 0u ? kFirstBatch : kWave;
                 const bool inb = lane < bw;
-                const bool endk = inb && ((ck > len) || (len - ck < 12u));   // :178
+                const bool endk = easy ? false : (inb && ((ck > len) || (len - ck < 12u)));   // :178
                 const bool active = inb && !endk;
                 uint64_t A0 = 0, A1 = 0;                                  // input[ck .. ck+16)
                 if (n == 0u && pf_c == c) { A0 = pfA0; A1 = pfA1; }
+                else if (easy) { if (inb) { A0 = ld8(in + ck); A1 = ld8(in + ck + 8u); } }
                 else if (active) { A0 = ld8(in + ck); A1 = ld8_part(ck + 8u); }   // >= 12 bytes remain
                 pf_c = 0xFFFFFFFFu;
                 const uint32_t h = TT::hash(A0);
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                 if (active) first = tab[h];
                 const bool dup = active && first != lane;
                 const uint32_t D = first_lane(__ballot(dup));             // 64 = no collision
-                const uint32_t e_end = first_lane(__ballot(endk));
+                const uint32_t e_end = easy ? 64u : first_lane(__ballot(endk));
                 // candidate the sequential algorithm would see at lane k (k <= D)
                 uint32_t cand;
                 {
@@ -183,7 +189,8 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                 uint64_t B0 = 0, B1 = 0, PA = 0, PB = 0;
                 const bool btfast = cand >= 8u;        // (then ck >= 8 as well)
                 if (reach) {
-                    B0 = ld8(in + cand); B1 = ld8_part(cand + 8u);
+                    B0 = ld8(in + cand);
+                    if (easy) B1 = ld8(in + cand + 8u); else B1 = ld8_part(cand + 8u);
                     if (btfast) { PA = ld8(in + ck - 8u); PB = ld8(in + cand - 8u); }
                 }
                 const bool valid = reach && (uint32_t)A0 == (uint32_t)B0;  // :204-206 (m >= 4)
@@ -207,7 +214,7 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                 else if (e_end < 64u) { commit_end = e_end; outcome = 2; }
                 else { commit_end = bw; outcome = 0; }
                 // EncoderTable contract (:67/:92): position + offset must fit the slot type
-                {
+                if (!easy) {
                     const bool bad = active && lane < commit_end && ((uint64_t)ck + base_off > TT::kLimit);
                     if (__ballot(bad)) { status = LZF_CONTRACT; }
                 }
@@ -315,7 +322,8 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
             {
                 const uint32_t ckn = cursor + lane;
                 pfA0 = 0; pfA1 = 0;
-                if (lane < kFirstBatch && ckn <= len && len - ckn >= 12u) { pfA0 = ld8(in + ckn); pfA1 = ld8_part(ckn + 8u); }
+                if ((uint64_t)cursor + kFirstBatch + 40u <= len) { if (lane < kFirstBatch) { pfA0 = ld8(in + ckn); pfA1 = ld8(in + ckn + 8u); } }
+                else if (lane < kFirstBatch && ckn <= len && len - ckn >= 12u) { pfA0 = ld8(in + ckn); pfA1 = ld8_part(ckn + 8u); }
                 pf_c = cursor;
             }
             // table.replace(input, cursor - 2) — unconditional (:218, quirks B1/B3)

@@ -27,6 +27,19 @@ def test_device_present():
     assert ffi.device_count() >= 1
 
 
+def test_plain_c_consumer_of_the_abi(tmp_path):
+    """examples/c_abi_roundtrip.c: the boundary from C with gcc — no Python, torch or C++ in the caller."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_abi_roundtrip")
+    libdir = os.path.join(root, "rust-lz-fear_amd")
+    subprocess.check_call(["gcc", "-O1", "-std=c11", "-Wall", os.path.join(root, "examples", "c_abi_roundtrip.c"),
+                           "-I", os.path.join(root, "include"), "-L", libdir, "-llzfear_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert "c abi ok" in r.stdout
+
+
 # ---------------------------------------------------------------- decompress
 def test_decode_kats():
     res = gpu_decompress([dict(input=d) for d, _, _ in vectors.DECODE_KATS])
