@@ -247,49 +247,40 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
             // handful of VALU per hop, and parked lanes are served together by the general routine.
             auto walk = [&](uint32_t p, const uint32_t end, uint32_t& n, uint32_t& k, bool& err, auto RECORD) -> uint32_t {
                 const uint32_t fast_end = len > 24u ? len - 24u : 0u;     // plain hops stay clear of the input's end
-                bool parked = false;
+                const uint32_t stop = end < fast_end ? end : fast_end;
                 for (;;) {
-                    for (;;) {
-                        const bool active = !parked && p < end && p < len;
-                        if (!__any(active)) break;
-                        if (active) {
-                            // plain view of the token: 4 bytes at p cover the token and its first literal-length
-                            // extension byte; a match-length extension byte costs one more read.  Anything
-                            // beyond that (0xFF runs, bodies leaving the staged bytes, the input's end) parks.
-                            bool simple = false;
-                            if (p < fast_end) {
-                                uint32_t w;
-                                if (STAGE) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(cbuf_a + (p - cstart)) : "memory");
-                                else w = ld4(in + p);
-                                uint32_t L = (w >> 4) & 15u;
-                                const uint32_t Mn = w & 15u, b1 = (w >> 8) & 255u;
-                                const bool ext = L == 15u;
-                                if (ext) L += b1;
-                                uint32_t q = p + 3u + (ext ? 1u : 0u) + L;          // first byte after the offset
-                                bool ok = !(ext && b1 == 255u) && q < fast_end && (!STAGE || (q - cstart) < kCB);
-                                if (ok && Mn == 15u) {
-                                    const uint32_t m1 = STAGE ? lds_ld8(cbuf_a + (q - cstart)) : (uint32_t)in[q];
-                                    ok = m1 != 255u;
-                                    ++q;
-                                }
-                                if (ok) {
-                                    simple = true;
-                                    if (RECORD.value) { if (k < (uint32_t)TOKCAP) toks[k] = (uint16_t)(p - cstart); else if (k == (uint32_t)TOKCAP) cutpos_w = p; ++k; }
-                                    ++n; p = q;
-                                }
-                            }
-                            if (!simple) parked = true;
+                    // plain hops: a per-lane loop the lane leaves when it is done or meets a token that needs
+                    // more than the 4-byte view (0xFF runs, bodies leaving the staged bytes)
+                    bool parked = false;
+                    while (p < stop) {
+                        uint32_t w;
+                        if (STAGE) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(cbuf_a + (p - cstart)) : "memory");
+                        else w = ld4(in + p);
+                        uint32_t L = (w >> 4) & 15u;
+                        const uint32_t Mn = w & 15u, b1 = (w >> 8) & 255u;
+                        const bool ext = L == 15u;
+                        if (ext) L += b1;
+                        uint32_t q = p + 3u + (ext ? 1u : 0u) + L;          // first byte after the offset
+                        bool ok = !(ext && b1 == 255u) && q < fast_end && (!STAGE || (q - cstart) < kCB);
+                        if (ok && Mn == 15u) {
+                            const uint32_t m1 = STAGE ? lds_ld8(cbuf_a + (q - cstart)) : (uint32_t)in[q];
+                            ok = m1 != 255u;
+                            ++q;
                         }
+                        if (!ok) { parked = true; break; }
+                        if (RECORD.value) { if (k < (uint32_t)TOKCAP) toks[k] = (uint16_t)(p - cstart); else if (k == (uint32_t)TOKCAP) cutpos_w = p; ++k; }
+                        ++n; p = q;
                     }
-                    if (!__any(parked)) break;
-                    if (parked) {
+                    // the general routine serves parked lanes and lanes near the end of the input
+                    const bool slow = parked || (p < end && p < len);
+                    if (!__any(slow)) break;
+                    if (slow) {
                         uint32_t nx;
                         if (!token_next(p, nx)) { err = true; p = len; }
                         else {
                             if (RECORD.value) { if (k < (uint32_t)TOKCAP) toks[k] = (uint16_t)(p - cstart); else if (k == (uint32_t)TOKCAP) cutpos_w = p; ++k; }
                             ++n; p = nx;
                         }
-                        parked = false;
                     }
                 }
                 return p;
