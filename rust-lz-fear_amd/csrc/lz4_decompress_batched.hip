@@ -341,10 +341,15 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 bool has = false;
                 if (act0) {
                     const uint32_t tp = cstart + toks[tidx + lane];
-                    const uint32_t tok = rdb(tp);
+                    const uint32_t w = rd4(tp);                      // token + first literal-length extension byte
+                    const uint32_t tok = w & 255u;
                     uint32_t q = tp + 1u;
                     L = tok >> 4;
-                    if (L == 15u) { for (;;) { const uint32_t b = rdb(q); ++q; L += b; if (L > kMaxPosB) L = kMaxPosB; if (b != 255u) break; } }
+                    if (L == 15u) {
+                        uint32_t b = (w >> 8) & 255u; ++q;
+                        L += b;
+                        while (b == 255u) { b = rdb(q); ++q; L += b; if (L > kMaxPosB) L = kMaxPosB; }
+                    }
                     src = q; q += L;
                     if (len - q >= 2u) {
                         has = true; q += 2u;
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 has = has && act;
                 if (!act) { L = 0; M = 0; }
                 uint32_t off = 0;
-                if (has) off = rdb(src + L) | (rdb(src + L + 1u) << 8);
+                if (has) { if (STAGE) off = rdb(src + L) | (rdb(src + L + 1u) << 8); else off = ld2(in + src + L); }
                 // ---- errors, first sequence in stream order wins; inside a sequence the reference's order
                 int code = LZF_OK;
                 if (act) {
