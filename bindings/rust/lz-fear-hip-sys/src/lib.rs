@@ -1,0 +1,72 @@
+//! FFI declarations of `include/lzfear_hip.h` (ABI version 1).  UNVERIFIED SOURCE: no Rust toolchain
+//! was available where this was written; field order and sizes mirror the C header
+//! (`lzf_compress_job` 56 B, `lzf_decompress_job` 64 B, `lzf_job_result` 16 B on LP64).
+#![allow(non_camel_case_types)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const LZF_OK: i32 = 0;
+pub const LZF_UNEXPECTED_END: i32 = 1; // DecodeError::UnexpectedEnd            src/raw/decompress.rs:9-10
+pub const LZF_MEMORY_LIMIT_EXCEEDED: i32 = 2; // DecodeError::MemoryLimitExceeded      :11-12
+pub const LZF_ZERO_DEDUP_OFFSET: i32 = 3; // DecodeError::ZeroDeduplicationOffset  :13-14
+pub const LZF_INVALID_DEDUP_OFFSET: i32 = 4; // DecodeError::InvalidDeduplicationOffset :15-16
+pub const LZF_OUTPUT_FULL: i32 = 5; // writer error (NoPartialWrites -> ConnectionAborted)
+pub const LZF_CONTRACT: i32 = 6; // the reference would panic (mod.rs:167, :67, :92)
+pub const LZF_OUT_CAPACITY: i32 = 7;
+pub const LZF_E_NO_DEVICE: c_int = -1;
+pub const LZF_E_HIP: c_int = -2;
+pub const LZF_E_INVALID: c_int = -3;
+pub const LZF_TABLE_U32: u32 = 0;
+pub const LZF_TABLE_U16: u32 = 1;
+pub const LZF_KINDS_U32: u32 = 1;
+pub const LZF_KINDS_U16: u32 = 2;
+pub const LZF_CJOB_TABLE_READONLY: u32 = 1;
+
+#[repr(C)]
+pub struct lzf_u32_table { pub dict: [u32; 4096], pub offset: u64 } // src/raw/compress/mod.rs:27-31
+#[repr(C)]
+pub struct lzf_u16_table { pub dict: [u16; 8192], pub offset: u64 } // :78-82
+
+#[repr(C)]
+pub struct lzf_compress_job {
+    pub input: *const u8,
+    pub input_len: u64,
+    pub cursor: u64,
+    pub out: *mut u8,
+    pub out_cap: u64,
+    pub table: *mut c_void,
+    pub table_kind: u32,
+    pub flags: u32,
+}
+
+#[repr(C)]
+pub struct lzf_decompress_job {
+    pub input: *const u8,
+    pub input_len: u64,
+    pub prefix: *const u8,
+    pub prefix_len: u64,
+    pub out: *mut u8,
+    pub out_existing_len: u64,
+    pub out_cap: u64,
+    pub output_limit: u64,
+}
+
+#[repr(C)]
+#[derive(Default, Clone, Copy)]
+pub struct lzf_job_result { pub out_len: u64, pub status: i32, pub reserved: u32 }
+
+extern "C" {
+    pub fn lzf_abi_version() -> c_int;
+    pub fn lzf_last_error() -> *const c_char;
+    pub fn lzf_device_count() -> c_int;
+    pub fn lzf_compress_batch(d_jobs: *const lzf_compress_job, d_results: *mut lzf_job_result, n_jobs: u32,
+                              table_kinds: u32, hip_stream: *mut c_void) -> c_int;
+    pub fn lzf_decompress_batch(d_jobs: *const lzf_decompress_job, d_results: *mut lzf_job_result, n_jobs: u32,
+                                hip_stream: *mut c_void) -> c_int;
+    pub fn lzf_compress_batch_host(jobs: *const lzf_compress_job, results: *mut lzf_job_result, n_jobs: u32) -> c_int;
+    pub fn lzf_decompress_batch_host(jobs: *const lzf_decompress_job, results: *mut lzf_job_result, n_jobs: u32) -> c_int;
+    pub fn lzf_table_seed_from_dictionary(d_table: *mut lzf_u32_table, d_dict: *const u8, dict_len: u64,
+                                          hip_stream: *mut c_void) -> c_int;
+    pub fn lzf_table_offset(d_table: *mut c_void, table_kind: u32, add: u64, hip_stream: *mut c_void) -> c_int;
+    pub fn lzf_xxh32_batch(d_ptrs: *const *const u8, d_lens: *const u64, d_out: *mut u32, n: u32,
+                           hip_stream: *mut c_void) -> c_int;
+}
