@@ -90,6 +90,11 @@ int lzf_frame_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, 
 
 /* XXH32 on the host (header / content checksums; twox-hash XxHash32 in the reference). */
 uint32_t lzf_xxh32(const uint8_t* p, size_t len, uint32_t seed);
+/* Streaming form (the content hasher of a block-by-block reader, src/framed/decompress.rs:89,276-278). */
+typedef struct lzf_xxh32_state { uint32_t v[4]; uint8_t buf[16]; uint32_t fill; uint32_t seed; uint64_t total; } lzf_xxh32_state;
+void lzf_xxh32_reset(lzf_xxh32_state* st, uint32_t seed);
+void lzf_xxh32_update(lzf_xxh32_state* st, const uint8_t* p, size_t len);
+uint32_t lzf_xxh32_digest(const lzf_xxh32_state* st);
 
 /* Frame assembly from already-compressed blocks (what rank 0 does after the RCCL all-gather of a
  * block-sharded compression): writes header, then for every block

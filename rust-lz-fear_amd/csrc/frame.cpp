@@ -103,6 +103,23 @@ extern "C" {
 
 uint32_t lzf_xxh32(const uint8_t* p, size_t len, uint32_t seed) { Xxh32 h(seed); h.update(p, len); return h.digest(); }
 
+static_assert(sizeof(lzf_xxh32_state) >= sizeof(uint32_t) * 4 + 16 + 4 + 4 + 8, "state layout");
+void lzf_xxh32_reset(lzf_xxh32_state* st, uint32_t seed) {
+    Xxh32 h(seed);
+    memcpy(st->v, h.v, sizeof st->v); st->fill = 0; st->seed = seed; st->total = 0;
+}
+void lzf_xxh32_update(lzf_xxh32_state* st, const uint8_t* p, size_t len) {
+    Xxh32 h(st->seed);
+    memcpy(h.v, st->v, sizeof h.v); memcpy(h.buf, st->buf, 16); h.fill = st->fill; h.total = st->total;
+    h.update(p, len);
+    memcpy(st->v, h.v, sizeof st->v); memcpy(st->buf, h.buf, 16); st->fill = h.fill; st->total = h.total;
+}
+uint32_t lzf_xxh32_digest(const lzf_xxh32_state* st) {
+    Xxh32 h(st->seed);
+    memcpy(h.v, st->v, sizeof h.v); memcpy(h.buf, st->buf, 16); h.fill = st->fill; h.total = st->total;
+    return h.digest();
+}
+
 void lzf_settings_default(lzf_settings* s) {
     memset(s, 0, sizeof *s);
     s->independent_blocks = 1; s->block_checksums = 0; s->content_checksum = 1;

@@ -72,7 +72,12 @@ EXPORTS = [
 FRAME_EXPORTS = [
     "lzf_settings_default", "lzf_frame_compress_bound", "lzf_frame_compress", "lzf_frame_read_header",
     "lzf_frame_decompress", "lzf_xxh32", "lzf_frame_assemble",
+    "lzf_xxh32_reset", "lzf_xxh32_update", "lzf_xxh32_digest",
 ]
+
+
+class Xxh32State(C.Structure):
+    _fields_ = [("v", C.c_uint32 * 4), ("buf", C.c_uint8 * 16), ("fill", C.c_uint32), ("seed", C.c_uint32), ("total", C.c_uint64)]
 
 _lib = None
 
@@ -113,6 +118,12 @@ def lib():
                                            C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.lzf_xxh32.restype = C.c_uint32
         L.lzf_xxh32.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
+        L.lzf_xxh32_reset.argtypes = [C.POINTER(Xxh32State), C.c_uint32]
+        L.lzf_xxh32_reset.restype = None
+        L.lzf_xxh32_update.argtypes = [C.POINTER(Xxh32State), C.c_char_p, C.c_size_t]
+        L.lzf_xxh32_update.restype = None
+        L.lzf_xxh32_digest.argtypes = [C.POINTER(Xxh32State)]
+        L.lzf_xxh32_digest.restype = C.c_uint32
         L.lzf_frame_assemble.argtypes = [C.POINTER(Settings), C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
                                          C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         _lib = L

@@ -121,3 +121,167 @@ def decompress_frame(frame, dictionary=b"", cap=None):
     if rc != 0:
         raise FrameError(rc, out.raw[: n.value])
     return out.raw[: n.value]
+
+
+class LZ4FrameReader:
+    """Block-by-block frame reader — `LZ4FrameReader` + `LZ4FrameIoReader` of the reference
+    (src/framed/decompress.rs:46-77,82-280) over a file-like object: `read(n)`, `fill_buf()`,
+    `consume(n)`, `block_size()`, `frame_size()`, `dictionary_id()`.
+
+    The reference decodes one block per `fill_buf`; one GPU launch per block would waste the device,
+    so independent-block frames are read ahead `readahead` blocks at a time and decoded as one batch
+    (errors still surface at the block where the reference would report them).  Linked-block frames
+    are sequential by construction and go block by block with the 64 KiB window as prefix."""
+
+    def __init__(self, reader, dictionary=b"", readahead=16):
+        self._r = reader
+        self._dict = bytes(dictionary)
+        self._readahead = max(1, int(readahead))
+        hdr = self._read_exact(7)
+        flg = hdr[4] if len(hdr) > 4 else 0
+        extra = (8 if flg & 0x08 else 0) + (4 if flg & 0x01 else 0)
+        if len(hdr) == 7 and extra:
+            hdr += self._read_exact(extra, allow_short=True)
+        self.info = ffi.FrameInfo()
+        rc = ffi.lib().lzf_frame_read_header(hdr, len(hdr), C.byref(self.info))
+        if rc != 0:
+            raise FrameError(rc)
+        self._linked = not (self.info.flags & 0x20)
+        self._bsum = bool(self.info.flags & 0x10)
+        self._csum = bool(self.info.flags & 0x04)
+        self._hasher = ffi.Xxh32State()
+        ffi.lib().lzf_xxh32_reset(C.byref(self._hasher), 0)
+        self._window = b""                 # carryover_window (:90,:253-269)
+        self._ready = []                   # decoded blocks waiting to be handed out
+        self._pending_error = None
+        self._buffer = b""
+        self._taken = 0
+        self._finished = False
+
+    # ---- accessors (:167-175)
+    def block_size(self):
+        return int(self.info.block_maxsize)
+
+    def frame_size(self):
+        return int(self.info.content_size) if self.info.has_content_size else None
+
+    def dictionary_id(self):
+        return int(self.info.dictionary_id) if self.info.has_dictionary_id else None
+
+    def _read_exact(self, n, allow_short=False):
+        out = b""
+        while len(out) < n:
+            c = self._r.read(n - len(out))
+            if not c:
+                break
+            out += c
+        return out
+
+    def _scan_block(self):
+        """One block of the wire format (:205-235) -> ('end', checksum|None) | ('blk', data, compressed)."""
+        w = self._read_exact(4)
+        if len(w) < 4:
+            raise FrameError(16)
+        bl = int.from_bytes(w, "little")
+        if bl == 0:
+            want = None
+            if self._csum:
+                c = self._read_exact(4)
+                if len(c) < 4:
+                    raise FrameError(16)
+                want = int.from_bytes(c, "little")
+            return ("end", want)
+        compressed = not (bl & 0x80000000)
+        bl &= 0x7FFFFFFF
+        if bl > self.block_size():
+            raise FrameError(22)
+        data = self._read_exact(bl)
+        if len(data) < bl:
+            raise FrameError(16)
+        if self._bsum:
+            c = self._read_exact(4)
+            if len(c) < 4:
+                raise FrameError(16)
+            if int.from_bytes(c, "little") != ffi.lib().lzf_xxh32(data, len(data), 0):
+                raise FrameError(19)
+        return ("blk", data, compressed)
+
+    def _refill(self):
+        """Scan up to `readahead` blocks and decode the compressed ones in one batch (one block at a time
+        for linked frames).  Results, an EndMark or the first error are queued in stream order."""
+        scanned, tail = [], None
+        limit = 1 if self._linked else self._readahead
+        while len(scanned) < limit:
+            try:
+                b = self._scan_block()
+            except FrameError as e:
+                tail = e                      # reported after the blocks before it have been delivered
+                break
+            if b[0] == "end":
+                tail = b
+                break
+            scanned.append(b)
+        bmax = self.block_size()
+        if self._linked and not self._window:
+            self._window = self._dict                               # :239-241
+        prefix = self._window if self._linked else self._dict       # :238-245
+        items = [dict(input=d, prefix=prefix, limit=bmax, out_cap=bmax + len(d)) for (_, d, comp) in scanned if comp]
+        res = iter(ffi.decompress_blocks_host(items)) if items else iter(())
+        for (_, d, comp) in scanned:
+            if comp:
+                rc, out = next(res)
+                if rc != 0:
+                    self._ready.append(FrameError(rc))              # CodecError
+                    return
+            else:
+                out = d                                             # :250
+            if self._linked:                                        # window update :253-269
+                self._window = (self._window + out)[-WINDOW_SIZE:] if len(out) < WINDOW_SIZE else out[-WINDOW_SIZE:]
+            if len(out) > bmax:
+                self._ready.append(FrameError(22))                  # :272-274
+                return
+            self._ready.append(out)
+        if tail is not None:
+            self._ready.append(tail)
+
+    def fill_buf(self):
+        """BufRead::fill_buf (:64-71): the current decoded block (b"" at the end of the frame)."""
+        if self._taken == len(self._buffer) and not self._finished:
+            self._buffer, self._taken = b"", 0
+            if not self._ready:
+                self._refill()
+            item = self._ready[0]
+            if isinstance(item, FrameError):
+                raise item                                          # sticky
+            if isinstance(item, tuple):                             # EndMark: verify the content checksum (:206-213)
+                if item[1] is not None and item[1] != ffi.lib().lzf_xxh32_digest(C.byref(self._hasher)):
+                    self._ready[0] = FrameError(20)
+                    raise self._ready[0]
+                self._ready.pop(0)
+                self._finished = True
+            else:
+                self._ready.pop(0)
+                if self._csum:
+                    ffi.lib().lzf_xxh32_update(C.byref(self._hasher), item, len(item))    # :276-278
+                self._buffer = item
+        return self._buffer[self._taken:]
+
+    def consume(self, amt):
+        self._taken += amt
+        assert self._taken <= len(self._buffer), "You consumed more bytes than I even gave you!"   # :75
+
+    def read(self, n=-1):
+        """io::Read::read (:54-60) when n >= 0; read_to_end when n < 0 (a 0-byte block ends it, like the
+        reference's read_to_end)."""
+        if n is None or n < 0:
+            out = b""
+            while True:
+                b = self.fill_buf()
+                if not b:
+                    return out
+                out += b
+                self.consume(len(b))
+        b = self.fill_buf()
+        take = min(len(b), n)
+        self.consume(take)
+        return b[:take]

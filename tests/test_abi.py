@@ -48,6 +48,12 @@ def test_frame_layer_host_only_pieces(lib):
     lib.lzf_settings_default(C.byref(s))
     assert (s.independent_blocks, s.block_checksums, s.content_checksum, s.block_size) == (1, 0, 1, 4 << 20)
     hc = (xxhash.xxh32(bytes([0x64, 0x70])).intdigest() >> 8) & 0xFF
+    st = ffi.Xxh32State()
+    lib.lzf_xxh32_reset(C.byref(st), 0)
+    blob = bytes(range(256)) * 9
+    for a, b in ((0, 5), (5, 16), (16, 1000), (1000, len(blob))):
+        lib.lzf_xxh32_update(C.byref(st), blob[a:b], b - a)
+    assert lib.lzf_xxh32_digest(C.byref(st)) == xxhash.xxh32(blob).intdigest()
     frame = bytes.fromhex("04224d186470") + bytes([hc]) + bytes(4) + (0x02CC5D05).to_bytes(4, "little")   # empty default frame
     info = ffi.FrameInfo()
     assert lib.lzf_frame_read_header(frame, len(frame), C.byref(info)) == 0

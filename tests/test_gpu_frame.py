@@ -219,3 +219,51 @@ def test_config5_repeat256_linked_dictionary_and_u16():
     assert res[1] == o.compress2(sl, cursor=4096, kind=o.TABLE_U16)
     back = ffi.decompress_blocks_host([dict(input=res[0][1], limit=65535), dict(input=res[1][1], prefix=sl[:4096], limit=65535 - 4096)])
     assert back[0] == (0, sl) and back[1] == (0, sl[4096:])
+
+
+def test_streaming_reader_matches_decompress_frame():
+    """LZ4FrameReader (block-by-block, read-ahead batches) == decompress_frame, including errors."""
+    import io
+    data = synth.silesia_mix(60 << 20, (60 << 20) + 1_300_000).tobytes()
+    for kw in (dict(block_size=64 << 10), dict(block_size=64 << 10, independent_blocks=False),
+               dict(block_size=256 << 10, block_checksums=True), dict(block_size=64 << 10, content_checksum=False)):
+        f = o.frame_compress(data, o.make_settings(**kw))[1]
+        for ra in (1, 3, 64):
+            r = framed.LZ4FrameReader(io.BytesIO(f), readahead=ra)
+            assert r.block_size() == kw["block_size"] and r.frame_size() is None and r.dictionary_id() is None
+            got = b""
+            while True:                                   # examples/delz4.rs loop: fill_buf / consume
+                b = r.fill_buf()
+                if not b:
+                    break
+                got += b[:1000]; r.consume(min(1000, len(b)))
+            assert got == data
+        assert framed.LZ4FrameReader(io.BytesIO(f)).read() == data
+        # small reads through io::Read::read
+        r = framed.LZ4FrameReader(io.BytesIO(f), readahead=4)
+        got = b""
+        while True:
+            c = r.read(4096)
+            if not c:
+                break
+            got += c
+        assert got == data
+    # errors surface at the same block with the same kind
+    rng = np.random.default_rng(31)
+    f = o.frame_compress(data, o.make_settings(block_size=64 << 10, block_checksums=True))[1]
+    for _ in range(25):
+        m = mutate(rng, f)
+        erc, eout, _ = o.frame_decompress(m, cap=16 << 20)
+        got, rc = b"", 0
+        try:
+            r = framed.LZ4FrameReader(io.BytesIO(m), readahead=5)
+            got = r.read()
+        except framed.FrameError as e:
+            rc = e.code
+        assert rc == erc, (rc, erc)
+        if rc == 0:
+            assert got == eout
+    d = synth.gen_text_zipf(3, 70000).tobytes()
+    f = o.frame_compress(data, o.make_settings(block_size=64 << 10, independent_blocks=False, dictionary=d, dictionary_id=9))[1]
+    r = framed.LZ4FrameReader(io.BytesIO(f), dictionary=d)
+    assert r.dictionary_id() == 9 and r.read() == data
