@@ -36,29 +36,21 @@ int ensure_device() {
     return n;
 }
 
-// Kernel generation used by lzf_decompress_batch.  Tuning / A-B knob only (both generations
-// implement the same contract): LZF_DECOMPRESS_KERNEL = wave | batched16 (ring 16K, regions 128 B) | batched8 (8K, 128) |
-// batched8s (8K, 64) | batched4 (4K, 128) | batched4s (4K, 64) — these stage the input chunk in LDS —
-// and direct4 (4K, 128) | direct4w (4K, 256; the default) | direct8w | direct4t | direct2t | direct4s, which
-// read the compressed bytes from HBM/L2 directly and so fit 2-3x more wavefronts per CU.
+// Kernel variant used by lzf_decompress_batch.  Tuning / A-B knob only (every variant implements the same
+// contract): LZF_DECOMPRESS_KERNEL = wave (first generation, one sequence at a time) or one of the names in
+// LZF_DECOMPRESS_VARIANTS (kernels.h).  Unknown names select the default.
+enum { kVariantWave = 0, kVariantFirstBatched = 1 };
+#define LZF_DEFAULT_VARIANT "staged64"
 int decompress_variant() {
     static const int v = [] {
         const char* e = getenv("LZF_DECOMPRESS_KERNEL");
-        if (!e || !*e) return 41;
-        if (!strcmp(e, "wave")) return 0;
-        if (!strcmp(e, "batched8")) return 8;
-        if (!strcmp(e, "batched8s")) return 32;
-        if (!strcmp(e, "batched4")) return 4;
-        if (!strcmp(e, "batched4s")) return 5;
-        if (!strcmp(e, "batched16")) return 16;
-        if (!strcmp(e, "direct4")) return 40;
-        if (!strcmp(e, "direct4w")) return 41;
-        if (!strcmp(e, "direct8w")) return 42;
-        if (!strcmp(e, "direct4t")) return 43;
-        if (!strcmp(e, "direct2t")) return 44;
-        if (!strcmp(e, "direct4s")) return 45;
-        if (!strcmp(e, "direct2")) return 46;
-        return 41;
+        if (!e || !*e) e = LZF_DEFAULT_VARIANT;
+        if (!strcmp(e, "wave")) return (int)kVariantWave;
+        int id = kVariantFirstBatched, def = -1;
+#define LZF_NAME(NAME, R, S_, T, ST) if (!strcmp(e, #NAME)) return id; if (!strcmp(LZF_DEFAULT_VARIANT, #NAME)) def = id; ++id;
+        LZF_DECOMPRESS_VARIANTS(LZF_NAME)
+#undef LZF_NAME
+        return def;
     }();
     return v;
 }
@@ -103,20 +95,15 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
     int rc = ensure_device();
     if (rc < 0) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    switch (decompress_variant()) {
-        case 0: hipLaunchKernelGGL(lzf::lzf_decompress_wave_kernel, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
-        case 8: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<8192, 128, 1024, true>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
-        case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<4096, 128, 1024, true>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
-        case 5: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<4096, 64, 512, true>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
-        case 40: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<4096, 128, 1024, false>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
-        case 41: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<4096, 256, 2048, false>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
-        case 42: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<8192, 256, 2048, false>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
-        case 43: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<4096, 128, 512, false>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
-        case 44: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<2048, 128, 512, false>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
-        case 45: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<4096, 64, 512, false>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
-        case 46: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<2048, 128, 1024, false>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
-        case 32: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<8192, 64, 512, true>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
-        default: hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<16384, 128, 1024, true>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs); break;
+    const int variant = decompress_variant();
+    if (variant == kVariantWave) {
+        hipLaunchKernelGGL(lzf::lzf_decompress_wave_kernel, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs);
+    } else {
+        int id = kVariantFirstBatched;
+#define LZF_LAUNCH(NAME, R, S_, T, ST) \
+        if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<R, S_, T, ST>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs);
+        LZF_DECOMPRESS_VARIANTS(LZF_LAUNCH)
+#undef LZF_LAUNCH
     }
     HIP_TRY(hipGetLastError());
     return LZF_OK;

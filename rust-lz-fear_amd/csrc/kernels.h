@@ -8,19 +8,23 @@ __global__ void lzf_decompress_wave_kernel(const lzf_decompress_job* __restrict_
 template <int RING, int S, int TOKCAP, bool STAGE>
 __global__ void lzf_decompress_batched_kernel(const lzf_decompress_job* __restrict__ jobs,
                                               lzf_job_result* __restrict__ results, uint32_t n_jobs);
-#define LZF_EXT(R, S_, T, ST) extern template __global__ void lzf_decompress_batched_kernel<R, S_, T, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t)
-LZF_EXT(16384, 128, 1024, true);
-LZF_EXT(8192, 128, 1024, true);
-LZF_EXT(8192, 64, 512, true);
-LZF_EXT(4096, 128, 1024, true);
-LZF_EXT(4096, 64, 512, true);
-LZF_EXT(4096, 128, 1024, false);
-LZF_EXT(4096, 256, 2048, false);
-LZF_EXT(8192, 256, 2048, false);
-LZF_EXT(4096, 128, 512, false);
-LZF_EXT(2048, 128, 512, false);
-LZF_EXT(4096, 64, 512, false);
-LZF_EXT(2048, 128, 1024, false);
+// Tuning variants of the batched kernel: X(name, ring bytes, region bytes, token-list entries, chunk staged in LDS).
+// LZF_DECOMPRESS_KERNEL=<name> selects one (A/B knob; every variant implements the same contract).
+#define LZF_DECOMPRESS_VARIANTS(X) \
+    X(staged32, 4096, 32, 512, true)    \
+    X(staged48, 4096, 48, 640, true)    \
+    X(staged64, 4096, 64, 768, true)    \
+    X(staged80, 4096, 80, 1024, true)   \
+    X(staged96, 4096, 96, 1024, true)   \
+    X(staged128, 4096, 128, 1536, true) \
+    X(staged8k64, 8192, 64, 768, true)  \
+    X(staged8k96, 8192, 96, 1024, true) \
+    X(batched16, 16384, 128, 1024, true) \
+    X(direct4, 4096, 128, 1024, false)  \
+    X(direct4w, 4096, 256, 2048, false)
+#define LZF_EXT(NAME, R, S_, T, ST) extern template __global__ void lzf_decompress_batched_kernel<R, S_, T, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+LZF_DECOMPRESS_VARIANTS(LZF_EXT)
+#undef LZF_EXT
 template <int KIND>
 __global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
                                          lzf_job_result* __restrict__ results, uint32_t n_jobs);

@@ -35,6 +35,7 @@
 // (UnexpectedEnd), MemoryLimitExceeded, ZeroDeduplicationOffset, InvalidDeduplicationOffset
 // (decompress.rs:63-75,82-89); across sequences the first one in stream order wins.
 #include "lzf_device.h"
+#include "kernels.h"
 
 namespace lzf {
 
@@ -43,6 +44,9 @@ namespace {
 constexpr uint32_t kMaxPosB = 0x7FFFFF00u;
 constexpr uint32_t kShort = 32;          // bytes a lane moves by itself; longer runs are cooperative
 constexpr uint32_t kTotClamp = 1u << 25; // per-sequence output clamp inside the position scan
+#ifndef LZF_DBG_SKIP
+#define LZF_DBG_SKIP 0      // analysis builds only: bit0 batches, bit1 serial matches, bit2 far, bit3 literals, bit4 flush, bit5 round 1
+#endif
 
 // Exact per-lane copy of n (1..32) bytes between two non-overlapping LDS byte ranges, neither of
 // which wraps: two-ended pieces (first/last 8, 4 or 2 bytes), at most 4 reads + 4 writes.
@@ -85,6 +89,103 @@ __device__ __forceinline__ void put_small_glb(uint32_t dst, cgu8* g, uint32_t n)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The token-hop loop of the parse, hand-scheduled (direct variants: tokens are read from HBM/L2).
+// The scalar unit is shared by the CU's four SIMDs and is the scarce issue resource of this kernel;
+// hipcc keeps per-lane booleans as SGPR lane masks and spends ~22 SALU per hop on combining them.
+// Here exec stays full, every predicate lives in VCC straight out of a v_cmp and is consumed by
+// v_cndmask / v_addc, so a hop costs 2 SALU (the loop branches) and ~26 VALU.
+//   live      <=> p < lim            (lim = the lane's stop position, 0 once the lane leaves the loop)
+//   q          = position of the next token; forced to ~0 when the token needs more than this view
+//                (a 0xFF length byte) so that the single test q < fast_end rejects it
+//   a lane that cannot take its hop (end of region, end of input margin, 0xFF run) gets lim = 0 and
+//   keeps p; the caller serves it with the general routine.
+// decompress.rs:61-71 without the copies.
+// ---------------------------------------------------------------------------------------------
+#define LZF_HOP_HEAD(LD4, LD1, WAIT) \
+    "Lhop_loop%=:\n\t" \
+    "v_cmp_lt_u32 vcc, %[p], %[lim]\n\t" \
+    "s_cbranch_vccz Lhop_done%=\n\t" \
+    "v_min_u32 %[pa], %[pclamp], %[p]\n\t" \
+    LD4 WAIT \
+    "v_bfe_u32 %[t], %[w], 4, 4\n\t"                 /* literal-length nibble */ \
+    "v_bfe_u32 %[q], %[w], 8, 8\n\t"                 /* first extension byte */ \
+    "v_cmp_eq_u32 vcc, 15, %[t]\n\t" \
+    "v_add_u32 %[q], 1, %[q]\n\t" \
+    "v_cndmask_b32 %[q], 0, %[q], vcc\n\t" \
+    "v_add3_u32 %[q], %[pa], %[t], %[q]\n\t" \
+    "v_add_u32 %[q], 3, %[q]\n\t"                    /* first byte after the offset */ \
+    "v_and_b32 %[t], 0xfff0, %[w]\n\t" \
+    "v_cmp_eq_u32 vcc, 0xfff0, %[t]\n\t"             /* nibble 15 and extension 0xFF */ \
+    "v_cndmask_b32_e64 %[q], %[q], -1, vcc\n\t" \
+    "v_and_b32 %[t], 15, %[w]\n\t"                   /* match-length nibble */ \
+    "v_cmp_gt_u32 vcc, %[fend], %[q]\n\t" \
+    "v_cndmask_b32 %[t], 0, %[t], vcc\n\t" \
+    "v_cmp_eq_u32 vcc, 15, %[t]\n\t"                 /* needs the first match-length extension byte */ \
+    "v_cndmask_b32 %[m], %[pa], %[q], vcc\n\t" \
+    LD1 \
+    "v_addc_co_u32_e64 %[q], %[sx], 0, %[q], vcc\n\t" \
+    WAIT \
+    "v_cndmask_b32 %[m], 0, %[m], vcc\n\t" \
+    "v_cmp_eq_u32 vcc, 0xff, %[m]\n\t" \
+    "v_cndmask_b32_e64 %[q], %[q], -1, vcc\n\t" \
+    "v_cmp_lt_u32 vcc, %[p], %[lim]\n\t" \
+    "v_cndmask_b32 %[t], -1, %[q], vcc\n\t" \
+    "v_cmp_gt_u32 vcc, %[fend], %[t]\n\t"            /* vcc = the lane takes this hop */
+#define LZF_HOP_TAIL \
+    "v_addc_co_u32_e64 %[n], %[sx], 0, %[n], vcc\n\t" \
+    "v_cndmask_b32 %[p], %[p], %[q], vcc\n\t" \
+    "v_cndmask_b32 %[lim], 0, %[lim], vcc\n\t" \
+    "s_branch Lhop_loop%=\n" \
+    "Lhop_done%=:"
+#define LZF_HOP_GLB LZF_HOP_HEAD("global_load_dword %[w], %[pa], %[in]\n\t", "global_load_ubyte %[m], %[m], %[in]\n\t", "s_waitcnt vmcnt(0)\n\t")
+#define LZF_HOP_LDS LZF_HOP_HEAD("ds_read_b32 %[w], %[pa]\n\t", "ds_read_u8 %[m], %[m]\n\t", "s_waitcnt lgkmcnt(0)\n\t")
+#define LZF_HOP_RECORD \
+    "v_cndmask_b32 %[kk], -1, %[k], vcc\n\t" \
+    "v_addc_co_u32_e64 %[k], %[sx], 0, %[k], vcc\n\t" \
+    "v_cmp_gt_u32_e64 %[sx], %[cap], %[kk]\n\t" \
+    "v_subrev_u32 %[t], %[cstart], %[pa]\n\t" \
+    "v_lshl_add_u32 %[m], %[kk], 1, %[toksa]\n\t" \
+    "v_cndmask_b32_e64 %[m], %[dump], %[m], %[sx]\n\t" \
+    "ds_write_b16 %[m], %[t]\n\t" \
+    "v_cmp_eq_u32_e64 %[sx], %[cap], %[kk]\n\t" \
+    "v_cndmask_b32_e64 %[cut], %[cut], %[pa], %[sx]\n\t"
+// STAGED selects the LDS form: p, lim, fast_end, pclamp and `cut` are then LDS byte addresses of the staged
+// chunk (position - cstart + address of cbuf) and `cstart` is the address of cbuf.
+template <bool STAGED>
+__device__ __forceinline__ void hop_loop(uint32_t& p, uint32_t& lim, uint32_t& n, cgu8* in, uint32_t fast_end, uint32_t pclamp) {
+    uint32_t pa, w, q, t, m; uint64_t sx;
+    if (STAGED)
+        asm volatile(LZF_HOP_LDS LZF_HOP_TAIL
+                     : [p] "+v"(p), [lim] "+v"(lim), [n] "+v"(n), [pa] "=&v"(pa), [w] "=&v"(w), [q] "=&v"(q), [t] "=&v"(t), [m] "=&v"(m), [sx] "=&s"(sx)
+                     : [fend] "s"(fast_end), [pclamp] "s"(pclamp)
+                     : "vcc", "memory");
+    else
+        asm volatile(LZF_HOP_GLB LZF_HOP_TAIL
+                     : [p] "+v"(p), [lim] "+v"(lim), [n] "+v"(n), [pa] "=&v"(pa), [w] "=&v"(w), [q] "=&v"(q), [t] "=&v"(t), [m] "=&v"(m), [sx] "=&s"(sx)
+                     : [in] "s"(in), [fend] "s"(fast_end), [pclamp] "s"(pclamp)
+                     : "vcc", "memory");
+}
+// Same, recording the token positions (relative to cstart) at toks[k++]; positions past the list's
+// capacity go to the lane's dump slot and the position of token #cap is kept in `cut`.
+template <bool STAGED>
+__device__ __forceinline__ void hop_loop_record(uint32_t& p, uint32_t& lim, uint32_t& n, uint32_t& k, uint32_t& cut, cgu8* in,
+                                                uint32_t fast_end, uint32_t pclamp, uint32_t cstart, uint32_t toks_a, uint32_t cap, uint32_t dump_a) {
+    uint32_t pa, w, q, t, m, kk; uint64_t sx;
+    if (STAGED)
+        asm volatile(LZF_HOP_LDS LZF_HOP_RECORD LZF_HOP_TAIL
+                     : [p] "+v"(p), [lim] "+v"(lim), [n] "+v"(n), [k] "+v"(k), [cut] "+v"(cut), [pa] "=&v"(pa), [w] "=&v"(w), [q] "=&v"(q),
+                       [t] "=&v"(t), [m] "=&v"(m), [kk] "=&v"(kk), [sx] "=&s"(sx)
+                     : [fend] "s"(fast_end), [pclamp] "s"(pclamp), [cstart] "s"(cstart), [toksa] "s"(toks_a), [cap] "s"(cap), [dump] "v"(dump_a)
+                     : "vcc", "memory");
+    else
+        asm volatile(LZF_HOP_GLB LZF_HOP_RECORD LZF_HOP_TAIL
+                     : [p] "+v"(p), [lim] "+v"(lim), [n] "+v"(n), [k] "+v"(k), [cut] "+v"(cut), [pa] "=&v"(pa), [w] "=&v"(w), [q] "=&v"(q),
+                       [t] "=&v"(t), [m] "=&v"(m), [kk] "=&v"(kk), [sx] "=&s"(sx)
+                     : [in] "s"(in), [fend] "s"(fast_end), [pclamp] "s"(pclamp), [cstart] "s"(cstart), [toksa] "s"(toks_a), [cap] "s"(cap), [dump] "v"(dump_a)
+                     : "vcc", "memory");
+}
+
 struct No { static constexpr bool value = false; };
 struct Yes { static constexpr bool value = true; };
 
@@ -103,7 +204,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
     constexpr uint32_t kCBAlloc = STAGE ? kCB : 16u;
     __shared__ __attribute__((aligned(16))) uint8_t ring[RING];
     __shared__ __attribute__((aligned(16))) uint8_t cbuf[kCBAlloc];
-    __shared__ uint16_t toks[TOKCAP];
+    __shared__ uint16_t toks[TOKCAP + 64];               // + one dump slot per lane for predicated stores
 
     const uint32_t jid = blockIdx.x;
     if (jid >= n_jobs) return;
@@ -245,34 +346,37 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
             // Divergence control: a lane whose token needs more than the plain 4-byte view (length
             // extensions, end of input) parks; all other lanes keep hopping with one LDS read and a
             // handful of VALU per hop, and parked lanes are served together by the general routine.
-            auto walk = [&](uint32_t p, const uint32_t end, uint32_t& n, uint32_t& k, bool& err, auto RECORD) -> uint32_t {
+            auto walk = [&](uint32_t p, const uint32_t end, uint32_t& n, uint32_t& k, bool& err, bool go, auto RECORD) -> uint32_t {
                 const uint32_t fast_end = len > 24u ? len - 24u : 0u;     // plain hops stay clear of the input's end
                 const uint32_t stop = end < fast_end ? end : fast_end;
+                uint32_t pclamp = len - 4u;                               // where idle lanes load from (only used when stop > 0)
+                if (STAGE && pclamp > cstart + kCB - 4u) pclamp = cstart + kCB - 4u;
                 for (;;) {
-                    // plain hops: a per-lane loop the lane leaves when it is done or meets a token that needs
-                    // more than the 4-byte view (0xFF runs, bodies leaving the staged bytes)
-                    bool parked = false;
-                    while (p < stop) {
-                        uint32_t w;
-                        if (STAGE) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(cbuf_a + (p - cstart)) : "memory");
-                        else w = ld4(in + p);
-                        uint32_t L = (w >> 4) & 15u;
-                        const uint32_t Mn = w & 15u, b1 = (w >> 8) & 255u;
-                        const bool ext = L == 15u;
-                        if (ext) L += b1;
-                        uint32_t q = p + 3u + (ext ? 1u : 0u) + L;          // first byte after the offset
-                        bool ok = !(ext && b1 == 255u) && q < fast_end && (!STAGE || (q - cstart) < kCB);
-                        if (ok && Mn == 15u) {
-                            const uint32_t m1 = STAGE ? lds_ld8(cbuf_a + (q - cstart)) : (uint32_t)in[q];
-                            ok = m1 != 255u;
-                            ++q;
-                        }
-                        if (!ok) { parked = true; break; }
-                        if (RECORD.value) { if (k < (uint32_t)TOKCAP) toks[k] = (uint16_t)(p - cstart); else if (k == (uint32_t)TOKCAP) cutpos_w = p; ++k; }
-                        ++n; p = q;
+                    // Plain hops.  The scalar unit (one per CU) is the scarce issue resource of this kernel, so
+                    // the loop is uniform: every lane executes every iteration with exec full, idle lanes are
+                    // predicated with selects and load from a clamped address.  A lane goes idle when it is done
+                    // or meets a token that needs more than the 4-byte view (0xFF runs, bodies leaving the staged
+                    // bytes, the end of the input); such lanes are served below by the general routine.
+                    if (!STAGE) {
+                        uint32_t lim = go ? stop : 0u;
+                        if (RECORD.value) hop_loop_record<false>(p, lim, n, k, cutpos_w, in, fast_end, pclamp, cstart, lds_addr(toks), (uint32_t)TOKCAP,
+                                                                 lds_addr(toks) + 2u * ((uint32_t)TOKCAP + lane));
+                        else hop_loop<false>(p, lim, n, in, fast_end, pclamp);
+                    } else if (fast_end > cstart) {
+                        // LDS coordinates: position - cstart + address of cbuf (every quantity below is >= cstart)
+                        const uint32_t base = cbuf_a - cstart;
+                        const uint32_t fe = (fast_end < cstart + kCB ? fast_end : cstart + kCB) + base;
+                        uint32_t pl = p + base, lim = go ? stop + base : 0u;
+                        if (RECORD.value) {
+                            uint32_t cut = 0;
+                            hop_loop_record<true>(pl, lim, n, k, cut, in, fe, pclamp + base, cbuf_a, lds_addr(toks), (uint32_t)TOKCAP,
+                                                  lds_addr(toks) + 2u * ((uint32_t)TOKCAP + lane));
+                            if (cut) cutpos_w = cut - base;
+                        } else hop_loop<true>(pl, lim, n, in, fe, pclamp + base);
+                        p = pl - base;
                     }
                     // the general routine serves parked lanes and lanes near the end of the input
-                    const bool slow = parked || (p < end && p < len);
+                    const bool slow = go && p < end && p < len;      // includes every lane that left the hop loop early
                     if (!__any(slow)) break;
                     if (slow) {
                         uint32_t nx;
@@ -297,15 +401,19 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
             bool lerr = false;
             {
                 uint32_t nw = 0; bool ew = false;
-                start = walk(start, rbeg, nw, kdummy, ew, No{});      // warm-up: these tokens do not count
+                start = walk(start, rbeg, nw, kdummy, ew, true, No{});      // warm-up: these tokens do not count
             }
+            bool redo = true;                          // lanes whose start changed walk again; the others keep x, n
             for (uint32_t pass = 0; pass < 70u; ++pass) {
-                n = 0; lerr = false;
-                x = walk(start, rend, n, kdummy, lerr, No{});
+                if (redo) { n = 0; lerr = false; }
+                uint32_t n1 = 0; bool e1 = false;
+                const uint32_t x1 = walk(start, rend, n1, kdummy, e1, redo, No{});
+                if (redo) { x = x1; n = n1; lerr = e1; }
                 // true exits never decrease along the stream, so a lane starts at the largest exit
                 // before it (a long literal run hands its exit to every region it skips at once)
                 const uint32_t nstart = wave_prev(wave_scan_max(x), cstart);
-                if (__all(nstart == start)) break;     // this pass ran from the true starts
+                redo = nstart != start;
+                if (!__any(redo)) break;               // this pass ran from the true starts
                 start = nstart;
             }
             // token ranks in stream order
@@ -316,7 +424,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
             const uint32_t Tc = cut ? (uint32_t)TOKCAP : T;
             {   // record pass
                 uint32_t k = rank0, n2 = 0; bool e2 = false;
-                (void)walk(start, rend, n2, k, e2, Yes{});
+                (void)walk(start, rend, n2, k, e2, true, Yes{});
             }
             uint32_t cend;        // where the next chunk starts
             int cerr = LZF_OK;    // UnexpectedEnd right after the listed tokens
@@ -332,6 +440,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
             // B. batches of up to 64 sequences: lane j owns token tidx + j
             // =====================================================================
             uint32_t tidx = 0;
+            if (LZF_DBG_SKIP & 1) { tidx = Tc; o += Tc; }
             while (tidx < Tc && status == LZF_OK) {
                 const uint32_t ob0 = o;
                 const uint32_t nb_try = Tc - tidx < kWave ? Tc - tidx : kWave;
@@ -446,7 +555,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 PHASE(1);
 
                 // ---- literals -> ring (decompress.rs:65-67)
-                if (__ballot(L > 0u)) {
+                if (!(LZF_DBG_SKIP & 8) && __ballot(L > 0u)) {
                     const uint32_t n1 = L < kShort ? L : kShort;            // the lane's own share
                     const uint32_t ri = RIDX(lo);
                     if (n1 > 0u) {
@@ -498,7 +607,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                     if (__ballot(need > safe)) { wave_store_fence(); safe = ob0; }
                 }
                 // far (never overlapping: offset > ring history > length): HBM -> ring
-                if (__ballot(is_far)) {
+                if (!(LZF_DBG_SKIP & 4) && __ballot(is_far)) {
                     if (is_far && M <= kShort) {
                         if (mwrap) { for (uint32_t t = 0; t < M; ++t) ring[RIDX(mo + t)] = out[s0 + t]; }
                         else put_small_glb(ring_a + mi, out + s0, M);
@@ -526,7 +635,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 const unsigned long long slow_mask = __ballot(is_slow);
                 // round 1 (lane-parallel): every near, non-overlapping, short match whose source lies
                 // below the first unresolved match start H — on typical data almost all of them
-                if (unresolved) {
+                if (!(LZF_DBG_SKIP & 32) && unresolved) {
                     const uint32_t f = (uint32_t)__builtin_ctzll(unresolved);
                     const uint32_t H = __builtin_amdgcn_readlane(mo, f);      // everything below H is final
                     const uint32_t si = RIDX(s0);
@@ -542,6 +651,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                     const uint32_t si = RIDX(s0);
                     const bool solo_ok = is_near && M <= off && M <= kShort && !mwrap && !(si + M > (uint32_t)RING);
                     const unsigned long long solo_mask = __ballot(solo_ok);
+                    if (LZF_DBG_SKIP & 2) unresolved = 0;
                     while (unresolved) {
                         const uint32_t f = (uint32_t)__builtin_ctzll(unresolved);
                         const unsigned long long bit = 1ull << f;
@@ -594,7 +704,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 PHASE(4);
                 // ---- flush the batch ring -> HBM
                 o = ob0 + __builtin_amdgcn_readlane(incl, (nb - 1u) & 63u);
-                ring_flush(ob0, o);
+                if (!(LZF_DBG_SKIP & 16)) ring_flush(ob0, o);
                 tidx += nb;
                 PHASE(5);
             }
@@ -626,18 +736,8 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
     }
 }
 
-#define LZF_INST(R, S_, T, ST) template __global__ void lzf_decompress_batched_kernel<R, S_, T, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t)
-LZF_INST(16384, 128, 1024, true);
-LZF_INST(8192, 128, 1024, true);
-LZF_INST(8192, 64, 512, true);
-LZF_INST(4096, 128, 1024, true);
-LZF_INST(4096, 64, 512, true);
-LZF_INST(4096, 128, 1024, false);
-LZF_INST(4096, 256, 2048, false);
-LZF_INST(8192, 256, 2048, false);
-LZF_INST(4096, 128, 512, false);
-LZF_INST(2048, 128, 512, false);
-LZF_INST(4096, 64, 512, false);
-LZF_INST(2048, 128, 1024, false);
+#define LZF_INST(NAME, R, S_, T, ST) template __global__ void lzf_decompress_batched_kernel<R, S_, T, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+LZF_DECOMPRESS_VARIANTS(LZF_INST)
+#undef LZF_INST
 
 }  // namespace lzf

@@ -157,7 +157,7 @@ def test_decompress_overlap_offsets():
         assert e[0] == 0 and r == e
 
 
-@pytest.mark.parametrize("variant", ["wave", "batched4", "batched4s", "batched8", "batched8s", "batched16", "direct4", "direct4w", "direct8w", "direct4t", "direct2t", "direct4s", "direct2"])
+@pytest.mark.parametrize("variant", ["wave", "staged32", "staged48", "staged64", "staged80", "staged96", "staged128", "staged8k64", "staged8k96", "batched16", "direct4", "direct4w"])
 def test_every_decompress_kernel_generation(variant):
     """Both kernel generations (and every ring/region geometry) implement the same contract."""
     import subprocess, sys
