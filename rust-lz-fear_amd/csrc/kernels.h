@@ -11,7 +11,10 @@ __global__ void lzf_decompress_batched_kernel(const lzf_decompress_job* __restri
 // Tuning variants of the batched kernel: X(name, ring bytes, region bytes, token-list entries, chunk staged in LDS).
 // LZF_DECOMPRESS_KERNEL=<name> selects one (A/B knob; every variant implements the same contract).
 #define LZF_DECOMPRESS_VARIANTS(X) \
+    X(staged16, 4096, 16, 256, true)    \
+    X(staged24, 4096, 24, 384, true)    \
     X(staged32, 4096, 32, 512, true)    \
+    X(staged32r2, 2048, 32, 512, true)    \
     X(staged48, 4096, 48, 640, true)    \
     X(staged64, 4096, 64, 768, true)    \
     X(staged80, 4096, 80, 1024, true)   \

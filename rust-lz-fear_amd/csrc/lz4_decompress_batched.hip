@@ -68,6 +68,20 @@ __device__ __forceinline__ void put_small_lds(uint32_t dst, uint32_t srca, uint3
         lds_st8(dst, lds_ld8(srca));
     }
 }
+// A match is 4..32 bytes here: two classes only.
+__device__ __forceinline__ void put_match_lds(uint32_t dst, uint32_t srca, uint32_t n) {
+    if (n >= 8u) {
+        const bool big = n > 16u;
+        uint64_t v0, v1, v2, v3;
+        lds_ld64x4(srca, big ? srca + 8u : srca, big ? srca + n - 16u : srca, srca + n - 8u, v0, v1, v2, v3);
+        lds_st64(dst, v0);
+        if (big) { lds_st64(dst + 8u, v1); lds_st64(dst + n - 16u, v2); }
+        lds_st64(dst + n - 8u, v3);
+    } else {
+        uint32_t v0, v1; lds_ld32x2(srca, srca + n - 4u, v0, v1);
+        lds_st32(dst, v0); lds_st32(dst + n - 4u, v1);
+    }
+}
 // Same, source in global memory (unaligned loads; reads exactly [g, g+n)).
 __device__ __forceinline__ void put_small_glb(uint32_t dst, cgu8* g, uint32_t n) {
     if (n >= 8u) {
@@ -186,6 +200,58 @@ __device__ __forceinline__ void hop_loop_record(uint32_t& p, uint32_t& lim, uint
                      : "vcc", "memory");
 }
 
+// Staged variants precompute, for every byte position of the chunk, the distance to the next token
+// (nxt[], one byte per position, 255 = "not a plain token here": 0xFF length bytes, end of input, ...),
+// with all lanes busy and no dependent chain.  A hop of the walks is then one LDS byte read.
+// p, lim and pclamp are LDS byte addresses into nxt[] (position - cstart + address of nxt).
+#define LZF_THOP_HEAD \
+    "Lthop_loop%=:\n\t" \
+    "v_cmp_lt_u32 vcc, %[p], %[lim]\n\t" \
+    "s_cbranch_vccz Lthop_done%=\n\t" \
+    "v_min_u32 %[pa], %[pclamp], %[p]\n\t" \
+    "ds_read_u8 %[d], %[pa]\n\t" \
+    "s_waitcnt lgkmcnt(0)\n\t" \
+    "v_cndmask_b32 %[t], -1, %[d], vcc\n\t"          /* idle lanes: ~0 */ \
+    "v_cmp_gt_u32 vcc, 0xff, %[t]\n\t"               /* vcc = the lane takes this hop (live and not 255) */
+#define LZF_THOP_TAIL \
+    "v_addc_co_u32_e64 %[n], %[sx], 0, %[n], vcc\n\t" \
+    "v_cndmask_b32 %[t], 0, %[d], vcc\n\t" \
+    "v_add_u32 %[p], %[p], %[t]\n\t" \
+    "v_cndmask_b32 %[lim], 0, %[lim], vcc\n\t" \
+    "s_branch Lthop_loop%=\n" \
+    "Lthop_done%=:"
+__device__ __forceinline__ void thop_loop(uint32_t& p, uint32_t& lim, uint32_t& n, uint32_t pclamp) {
+    uint32_t pa, d, t; uint64_t sx;
+    asm volatile(LZF_THOP_HEAD LZF_THOP_TAIL
+                 : [p] "+v"(p), [lim] "+v"(lim), [n] "+v"(n), [pa] "=&v"(pa), [d] "=&v"(d), [t] "=&v"(t), [sx] "=&s"(sx)
+                 : [pclamp] "s"(pclamp)
+                 : "vcc", "memory");
+}
+// Same, recording token positions (chunk offsets) at toks[k++]; `cut` keeps the nxt[] address of token #cap.
+__device__ __forceinline__ void thop_loop_record(uint32_t& p, uint32_t& lim, uint32_t& n, uint32_t& k, uint32_t& cut, uint32_t pclamp,
+                                                 uint32_t nxt_a, uint32_t toks_a, uint32_t cap, uint32_t dump_a) {
+    uint32_t pa, d, t, m, kk; uint64_t sx;
+    asm volatile(LZF_THOP_HEAD
+                 "v_cndmask_b32 %[kk], -1, %[k], vcc\n\t"
+                 "v_addc_co_u32_e64 %[k], %[sx], 0, %[k], vcc\n\t"
+                 "v_cmp_gt_u32_e64 %[sx], %[cap], %[kk]\n\t"
+                 "v_subrev_u32 %[t], %[nxta], %[pa]\n\t"
+                 "v_lshl_add_u32 %[m], %[kk], 1, %[toksa]\n\t"
+                 "v_cndmask_b32_e64 %[m], %[dump], %[m], %[sx]\n\t"
+                 "ds_write_b16 %[m], %[t]\n\t"
+                 "v_cmp_eq_u32_e64 %[sx], %[cap], %[kk]\n\t"
+                 "v_cndmask_b32_e64 %[cut], %[cut], %[pa], %[sx]\n\t"
+                 LZF_THOP_TAIL
+                 : [p] "+v"(p), [lim] "+v"(lim), [n] "+v"(n), [k] "+v"(k), [cut] "+v"(cut), [pa] "=&v"(pa), [d] "=&v"(d), [t] "=&v"(t),
+                   [m] "=&v"(m), [kk] "=&v"(kk), [sx] "=&s"(sx)
+                 : [pclamp] "s"(pclamp), [nxta] "s"(nxt_a), [toksa] "s"(toks_a), [cap] "s"(cap), [dump] "v"(dump_a)
+                 : "vcc", "memory");
+}
+__device__ __forceinline__ void lds_ld8x4(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t& v0, uint32_t& v1, uint32_t& v2, uint32_t& v3) {
+    asm volatile("ds_read_u8 %0, %4\n\tds_read_u8 %1, %5\n\tds_read_u8 %2, %6\n\tds_read_u8 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
+}
+
 struct No { static constexpr bool value = false; };
 struct Yes { static constexpr bool value = true; };
 
@@ -204,6 +270,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
     constexpr uint32_t kCBAlloc = STAGE ? kCB : 16u;
     __shared__ __attribute__((aligned(16))) uint8_t ring[RING];
     __shared__ __attribute__((aligned(16))) uint8_t cbuf[kCBAlloc];
+    __shared__ __attribute__((aligned(16))) uint8_t nxt[STAGE ? kChunk : 16u];   // staged variants: distance to the next token per position
     __shared__ uint16_t toks[TOKCAP + 64];               // + one dump slot per lane for predicated stores
 
     const uint32_t jid = blockIdx.x;
@@ -228,7 +295,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
         const uint32_t cap = job.out_cap > kMaxPosB ? kMaxPosB : (uint32_t)job.out_cap;
         const uint64_t limit = job.output_limit;
         const uint32_t rb = (uint32_t)(reinterpret_cast<uintptr_t>(out) & 15u);   // ring bias
-        const uint32_t ring_a = lds_addr(ring), cbuf_a = lds_addr(cbuf);
+        const uint32_t ring_a = lds_addr(ring), cbuf_a = lds_addr(cbuf), nxt_a = lds_addr(nxt);
 #define RIDX(x) (((x) + rb) & kMask)
 
         // ring <- out[a, b)   (b - a <= RING; caller made out[a,b) visible)
@@ -287,6 +354,39 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                         const uint32_t i = base + k * 1024u + lane * 16u;
                         if (i < kCB) *reinterpret_cast<u32x4*>(&cbuf[i]) = v[k];
                     }
+                }
+            }
+            // =====================================================================
+            // A1. next-token table of the chunk (decompress.rs:61-71 without the copies, plain tokens only)
+            // =====================================================================
+            if (STAGE) {
+                const uint32_t fast_end = len > 24u ? len - 24u : 0u;
+                const uint32_t fe = fast_end < cstart + kCB ? fast_end : cstart + kCB;     // a plain token's body ends below fe
+#pragma unroll 1
+                for (uint32_t j = lane * 4u; j < kChunk; j += 4u * kWave) {
+                    const uint32_t w0 = *reinterpret_cast<const uint32_t*>(&cbuf[j]);
+                    const uint32_t w1 = *reinterpret_cast<const uint32_t*>(&cbuf[j + 4u]);
+                    uint32_t d[4], qa[4], m1[4]; bool bad[4], need[4];
+#pragma unroll
+                    for (uint32_t t = 0; t < 4u; ++t) {
+                        const uint32_t w = t == 0 ? w0 : __builtin_amdgcn_alignbyte(w1, w0, t);   // bytes j+t, j+t+1, ...
+                        const uint32_t L0 = (w >> 4) & 15u, b1 = (w >> 8) & 255u;
+                        const bool ext = L0 == 15u;
+                        d[t] = 3u + L0 + (ext ? b1 + 1u : 0u);                  // to the first byte after the offset
+                        const uint32_t q = cstart + j + t + d[t];
+                        bad[t] = (ext && b1 == 255u) || q >= fe;
+                        need[t] = (w & 15u) == 15u;
+                        qa[t] = bad[t] ? 0u : q - cstart;
+                    }
+                    lds_ld8x4(cbuf_a + qa[0], cbuf_a + qa[1], cbuf_a + qa[2], cbuf_a + qa[3], m1[0], m1[1], m1[2], m1[3]);
+                    uint32_t o4 = 0;
+#pragma unroll
+                    for (uint32_t t = 0; t < 4u; ++t) {
+                        const uint32_t dd = d[t] + (need[t] ? 1u : 0u);
+                        const bool b = bad[t] || (need[t] && m1[t] == 255u) || dd > 254u;
+                        o4 |= (b ? 255u : dd) << (8u * t);
+                    }
+                    *reinterpret_cast<uint32_t*>(&nxt[j]) = o4;
                 }
             }
             // byte of the input at absolute position q >= cstart
@@ -362,17 +462,16 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                         if (RECORD.value) hop_loop_record<false>(p, lim, n, k, cutpos_w, in, fast_end, pclamp, cstart, lds_addr(toks), (uint32_t)TOKCAP,
                                                                  lds_addr(toks) + 2u * ((uint32_t)TOKCAP + lane));
                         else hop_loop<false>(p, lim, n, in, fast_end, pclamp);
-                    } else if (fast_end > cstart) {
-                        // LDS coordinates: position - cstart + address of cbuf (every quantity below is >= cstart)
-                        const uint32_t base = cbuf_a - cstart;
-                        const uint32_t fe = (fast_end < cstart + kCB ? fast_end : cstart + kCB) + base;
+                    } else {
+                        // nxt[] coordinates: position - cstart + address of nxt
+                        const uint32_t base = nxt_a - cstart;
                         uint32_t pl = p + base, lim = go ? stop + base : 0u;
                         if (RECORD.value) {
                             uint32_t cut = 0;
-                            hop_loop_record<true>(pl, lim, n, k, cut, in, fe, pclamp + base, cbuf_a, lds_addr(toks), (uint32_t)TOKCAP,
-                                                  lds_addr(toks) + 2u * ((uint32_t)TOKCAP + lane));
+                            thop_loop_record(pl, lim, n, k, cut, nxt_a + kChunk - 1u, nxt_a, lds_addr(toks), (uint32_t)TOKCAP,
+                                             lds_addr(toks) + 2u * ((uint32_t)TOKCAP + lane));
                             if (cut) cutpos_w = cut - base;
-                        } else hop_loop<true>(pl, lim, n, in, fe, pclamp + base);
+                        } else thop_loop(pl, lim, n, nxt_a + kChunk - 1u);
                         p = pl - base;
                     }
                     // the general routine serves parked lanes and lanes near the end of the input
@@ -633,33 +732,29 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 PHASE(3);
                 unsigned long long unresolved = __ballot(is_near || is_slow);
                 const unsigned long long slow_mask = __ballot(is_slow);
-                // round 1 (lane-parallel): every near, non-overlapping, short match whose source lies
-                // below the first unresolved match start H — on typical data almost all of them
-                if (!(LZF_DBG_SKIP & 32) && unresolved) {
-                    const uint32_t f = (uint32_t)__builtin_ctzll(unresolved);
-                    const uint32_t H = __builtin_amdgcn_readlane(mo, f);      // everything below H is final
-                    const uint32_t si = RIDX(s0);
-                    const bool fast = is_near && (s0 + span <= H) && M <= off && M <= kShort &&
-                                      !mwrap && !(si + M > (uint32_t)RING);
-                    if (fast) put_small_lds(ring_a + mi, ring_a + si, M);
-                    unresolved &= ~__ballot(fast);
-                }
-                // the rest strictly in stream order.  LDS runs one wave's accesses in order, so a dependent
-                // copy only has to be issued after the copies it reads from: the owning lane moves a short
-                // non-overlapping match by itself (two-ended pieces), everything else is cooperative.
+                // Rounds in stream order.  H = start of the first unresolved match: every output byte below H is
+                // final, so each round moves, all lanes at once, every short non-overlapping near match whose
+                // source ends at or below H (on typical data most matches go in the first round; ~6 rounds per
+                // batch on the Silesia stand-in).  When the first unresolved match is not of that kind (long,
+                // overlapping, wrapping, prefix / straddling source) the wave moves that one cooperatively.
+                // LDS runs one wave's accesses in order, so no wait separates dependent rounds.
                 {
                     const uint32_t si = RIDX(s0);
                     const bool solo_ok = is_near && M <= off && M <= kShort && !mwrap && !(si + M > (uint32_t)RING);
                     const unsigned long long solo_mask = __ballot(solo_ok);
+                    const uint32_t src_end = s0 + span;
                     if (LZF_DBG_SKIP & 2) unresolved = 0;
                     while (unresolved) {
                         const uint32_t f = (uint32_t)__builtin_ctzll(unresolved);
                         const unsigned long long bit = 1ull << f;
-                        unresolved &= ~bit;
                         if (solo_mask & bit) {
-                            if (lane == f) put_small_lds(ring_a + mi, ring_a + si, M);
+                            const uint32_t H = __builtin_amdgcn_readlane(mo, f);
+                            const unsigned long long go = __ballot(solo_ok && src_end <= H) & unresolved;   // includes lane f
+                            if ((go >> lane) & 1ull) put_match_lds(ring_a + mi, ring_a + si, M);
+                            unresolved &= ~go;
                             continue;
                         }
+                        unresolved &= ~bit;
                         if (slow_mask & bit) {
                             // prefix / straddling source: one lane, byte-serial, three sources
                             if (lane == f) {
