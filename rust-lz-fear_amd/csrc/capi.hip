@@ -40,7 +40,7 @@ int ensure_device() {
 // contract): LZF_DECOMPRESS_KERNEL = wave (first generation, one sequence at a time) or one of the names in
 // LZF_DECOMPRESS_VARIANTS (kernels.h).  Unknown names select the default.
 enum { kVariantWave = 0, kVariantFirstBatched = 1 };
-#define LZF_DEFAULT_VARIANT "staged32"
+#define LZF_DEFAULT_VARIANT "staged16"
 int decompress_variant() {
     static const int v = [] {
         const char* e = getenv("LZF_DECOMPRESS_KERNEL");

@@ -14,15 +14,10 @@ __global__ void lzf_decompress_batched_kernel(const lzf_decompress_job* __restri
     X(staged16, 4096, 16, 256, true)    \
     X(staged24, 4096, 24, 384, true)    \
     X(staged32, 4096, 32, 512, true)    \
-    X(staged32r2, 2048, 32, 512, true)    \
+    X(staged32r2, 2048, 32, 512, true)  \
     X(staged48, 4096, 48, 640, true)    \
     X(staged64, 4096, 64, 768, true)    \
-    X(staged80, 4096, 80, 1024, true)   \
-    X(staged96, 4096, 96, 1024, true)   \
-    X(staged128, 4096, 128, 1536, true) \
     X(staged8k64, 8192, 64, 768, true)  \
-    X(staged8k96, 8192, 96, 1024, true) \
-    X(batched16, 16384, 128, 1024, true) \
     X(direct4, 4096, 128, 1024, false)  \
     X(direct4w, 4096, 256, 2048, false)
 #define LZF_EXT(NAME, R, S_, T, ST) extern template __global__ void lzf_decompress_batched_kernel<R, S_, T, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t);

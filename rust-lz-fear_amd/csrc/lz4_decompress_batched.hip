@@ -271,7 +271,14 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
     __shared__ __attribute__((aligned(16))) uint8_t ring[RING];
     __shared__ __attribute__((aligned(16))) uint8_t cbuf[kCBAlloc];
     __shared__ __attribute__((aligned(16))) uint8_t nxt[STAGE ? kChunk : 16u];   // staged variants: distance to the next token per position
-    __shared__ uint16_t toks[TOKCAP + 64];               // + one dump slot per lane for predicated stores
+    // toks: token list (+ one dump slot per lane for predicated stores).  Staged variants first use the same
+    // bytes for ex[]: per region a table "entry offset -> exit", padded to S + 4 bytes per lane so that the
+    // 64 lanes hit 64 different banks when they all touch the same offset.
+    constexpr uint32_t kExStride = (uint32_t)S + 4u;
+    constexpr uint32_t kTokBytes = ((uint32_t)TOKCAP + 64u) * 2u;
+    constexpr uint32_t kExBytes = STAGE ? 64u * kExStride : 0u;
+    __shared__ __attribute__((aligned(16))) uint8_t tokex[kTokBytes > kExBytes ? kTokBytes : kExBytes];
+    uint16_t* const toks = reinterpret_cast<uint16_t*>(tokex);
 
     const uint32_t jid = blockIdx.x;
     if (jid >= n_jobs) return;
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
         const uint32_t cap = job.out_cap > kMaxPosB ? kMaxPosB : (uint32_t)job.out_cap;
         const uint64_t limit = job.output_limit;
         const uint32_t rb = (uint32_t)(reinterpret_cast<uintptr_t>(out) & 15u);   // ring bias
-        const uint32_t ring_a = lds_addr(ring), cbuf_a = lds_addr(cbuf), nxt_a = lds_addr(nxt);
+        const uint32_t ring_a = lds_addr(ring), cbuf_a = lds_addr(cbuf), nxt_a = lds_addr(nxt), ex_a = lds_addr(tokex);
 #define RIDX(x) (((x) + rb) & kMask)
 
         // ring <- out[a, b)   (b - a <= RING; caller made out[a,b) visible)
@@ -493,11 +500,66 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
             // =====================================================================
             const uint32_t rbeg = cstart + lane * (uint32_t)S;
             const uint32_t rend = rbeg + (uint32_t)S;
+            uint32_t start, x = 0, n = 0, kdummy = 0;
+            bool lerr = false;
+            if (STAGE) {
+                // A2. per region, exit of the token chain for every entry offset, by one backward sweep over nxt[]
+                // (a token is at least 3 bytes, so position p only depends on positions > p):
+                //   ex[p] = exit - rend (0..253) | 254: exits further away | 255: meets a token the table cannot express
+                const uint32_t exl = ex_a + lane * kExStride;
+                const uint32_t nxl = nxt_a + lane * (uint32_t)S;
+                // per dword of nxt[]: positions 3, 2, 1 never depend on each other (a token is >= 3 bytes), position 0
+                // may depend on position 3 — two LDS round trips per four positions
+#pragma unroll 1
+                for (int wq = S / 4 - 1; wq >= 0; --wq) {
+                    const uint32_t w4 = *reinterpret_cast<const uint32_t*>(&nxt[lane * (uint32_t)S + 4u * (uint32_t)wq]);
+                    const uint32_t p0 = 4u * (uint32_t)wq;
+                    uint32_t d[4], t[4], e[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; ++u) { d[u] = (w4 >> (8u * u)) & 255u; t[u] = p0 + u + d[u]; }
+                    lds_ld8x4(exl + (t[3] < (uint32_t)S ? t[3] : p0), exl + (t[2] < (uint32_t)S ? t[2] : p0),
+                              exl + (t[1] < (uint32_t)S ? t[1] : p0), exl + p0, e[3], e[2], e[1], e[0]);
+#pragma unroll
+                    for (uint32_t u = 3; u >= 1u; --u) {
+                        if (t[u] >= (uint32_t)S) e[u] = t[u] - (uint32_t)S < 254u ? t[u] - (uint32_t)S : 254u;
+                        if (d[u] == 255u) e[u] = 255u;
+                        lds_st8(exl + p0 + u, e[u]);
+                    }
+                    e[0] = lds_ld8(exl + (t[0] < (uint32_t)S ? t[0] : p0));
+                    if (t[0] >= (uint32_t)S) e[0] = t[0] - (uint32_t)S < 254u ? t[0] - (uint32_t)S : 254u;
+                    if (d[0] == 255u) e[0] = 255u;
+                    lds_st8(exl + p0, e[0]);
+                }
+                // A3. fixed point over the region starts with one table lookup per lane and pass:
+                //   start[i+1] = max(exit[0..i]); lane 0 starts at a true token, so the fixed point is the true chain.
+                start = lane == 0 ? cstart : rbeg;
+                bool redo = true;
+                for (uint32_t pass = 0; pass < 70u; ++pass) {
+                    bool hard = false;
+                    if (redo) {
+                        if (start >= rend) x = start;                 // the chain jumps over this region
+                        else {
+                            const uint32_t e = lds_ld8(exl + (start - rbeg));
+                            x = rend + e;
+                            hard = e >= 254u;
+                        }
+                    }
+                    if (__any(hard)) {                                // rare: walk it (0xFF runs, long literals, end of input)
+                        uint32_t n1 = 0; bool e1 = false;
+                        const uint32_t x1 = walk(start, rend, n1, kdummy, e1, hard, No{});
+                        if (hard) x = x1;
+                    }
+                    const uint32_t nstart = wave_prev(wave_scan_max(x), cstart);
+                    redo = nstart != start;
+                    if (!__any(redo)) break;
+                    start = nstart;
+                }
+                // A4. count the tokens of every region from its true start (also finds UnexpectedEnd)
+                x = walk(start, rend, n, kdummy, lerr, true, No{});
+            } else {
             // First guess: walk in from the previous region's start (for lane 1 that is a true token),
             // so that the chain has usually re-synchronised by the time it enters the lane's region.
-            uint32_t start = lane == 0 ? cstart : rbeg - (uint32_t)S;
-            uint32_t x = 0, n = 0, kdummy = 0;
-            bool lerr = false;
+            start = lane == 0 ? cstart : rbeg - (uint32_t)S;
             {
                 uint32_t nw = 0; bool ew = false;
                 start = walk(start, rbeg, nw, kdummy, ew, true, No{});      // warm-up: these tokens do not count
@@ -514,6 +576,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 redo = nstart != start;
                 if (!__any(redo)) break;               // this pass ran from the true starts
                 start = nstart;
+            }
             }
             // token ranks in stream order
             const uint32_t incl_n = wave_scan_add(n);
