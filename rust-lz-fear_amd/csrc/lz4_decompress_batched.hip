@@ -716,6 +716,38 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 if (e < 64u) { status = __builtin_amdgcn_readlane(code, e); break; }
                 PHASE(1);
 
+                // ---- matches (copy_overlapping, decompress.rs:80-138)
+                const uint32_t near_lo = ob0 > kNearHist ? ob0 - kNearHist : 0u;
+                const uint32_t span = M < off ? M : off;                  // distinct source bytes
+                const bool from_prefix = has && off > mo;
+                const uint32_t s0 = mo - off;                             // valid when !from_prefix
+                const bool is_near = has && !from_prefix && s0 >= near_lo;
+                const bool is_far = has && !from_prefix && s0 + span <= near_lo;
+                const bool is_slow = has && !is_near && !is_far;          // prefix or straddling
+                const uint32_t mi = RIDX(mo);
+                const bool mwrap = mi + M > (uint32_t)RING;               // destination wraps around the ring
+                // HBM visibility of what far / slow lanes read back
+                {
+                    uint32_t need = 0;
+                    if (is_far) need = s0 + M;
+                    if (is_slow && !from_prefix) need = near_lo;
+                    if (is_slow && from_prefix && M > off - mo) need = near_lo;
+                    if (need > ob0) need = ob0;
+                    if (__ballot(need > safe)) { wave_store_fence(); safe = ob0; }
+                }
+                // far (never overlapping: offset > ring history > length): HBM -> ring.  The loads of the short
+                // ones are issued here and land while the literals are being copied; the stores follow below.
+                const bool far_own = !(LZF_DBG_SKIP & 4) && is_far && M <= kShort && !mwrap;
+                uint64_t fv0 = 0, fv1 = 0, fv2 = 0, fv3 = 0;
+                if (far_own) {
+                    cgu8* g = out + s0;
+                    if (M >= 8u) {
+                        fv0 = ld8(g); fv3 = ld8(g + M - 8u);
+                        if (M > 16u) { fv1 = ld8(g + 8u); fv2 = ld8(g + M - 16u); }
+                    } else {
+                        fv0 = ld4(g); fv3 = ld4(g + M - 4u);
+                    }
+                }
                 // ---- literals -> ring (decompress.rs:65-67)
                 if (!(LZF_DBG_SKIP & 8) && __ballot(L > 0u)) {
                     const uint32_t n1 = L < kShort ? L : kShort;            // the lane's own share
@@ -749,31 +781,18 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 }
                 PHASE(2);
 
-                // ---- matches (copy_overlapping, decompress.rs:80-138)
-                const uint32_t near_lo = ob0 > kNearHist ? ob0 - kNearHist : 0u;
-                const uint32_t span = M < off ? M : off;                  // distinct source bytes
-                const bool from_prefix = has && off > mo;
-                const uint32_t s0 = mo - off;                             // valid when !from_prefix
-                const bool is_near = has && !from_prefix && s0 >= near_lo;
-                const bool is_far = has && !from_prefix && s0 + span <= near_lo;
-                const bool is_slow = has && !is_near && !is_far;          // prefix or straddling
-                const uint32_t mi = RIDX(mo);
-                const bool mwrap = mi + M > (uint32_t)RING;               // destination wraps around the ring
-                // HBM visibility of what far / slow lanes read back
-                {
-                    uint32_t need = 0;
-                    if (is_far) need = s0 + M;
-                    if (is_slow && !from_prefix) need = near_lo;
-                    if (is_slow && from_prefix && M > off - mo) need = near_lo;
-                    if (need > ob0) need = ob0;
-                    if (__ballot(need > safe)) { wave_store_fence(); safe = ob0; }
-                }
-                // far (never overlapping: offset > ring history > length): HBM -> ring
-                if (!(LZF_DBG_SKIP & 4) && __ballot(is_far)) {
-                    if (is_far && M <= kShort) {
-                        if (mwrap) { for (uint32_t t = 0; t < M; ++t) ring[RIDX(mo + t)] = out[s0 + t]; }
-                        else put_small_glb(ring_a + mi, out + s0, M);
+                if (far_own) {
+                    const uint32_t dsta = ring_a + mi;
+                    if (M >= 8u) {
+                        lds_st64(dsta, fv0);
+                        if (M > 16u) { lds_st64(dsta + 8u, fv1); lds_st64(dsta + M - 16u, fv2); }
+                        lds_st64(dsta + M - 8u, fv3);
+                    } else {
+                        lds_st32(dsta, (uint32_t)fv0); lds_st32(dsta + M - 4u, (uint32_t)fv3);
                     }
+                }
+                if (!(LZF_DBG_SKIP & 4) && __ballot(is_far && !far_own)) {
+                    if (is_far && M <= kShort && mwrap) { for (uint32_t t = 0; t < M; ++t) ring[RIDX(mo + t)] = out[s0 + t]; }
                     for (unsigned long long m = __ballot(is_far && M > kShort); m; m &= m - 1ull) {
                         const uint32_t j = (uint32_t)__builtin_ctzll(m);
                         const uint32_t jm = __builtin_amdgcn_readlane(M, j);
