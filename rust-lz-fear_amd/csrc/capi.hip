@@ -39,7 +39,7 @@ int ensure_device() {
 // Kernel variant used by lzf_decompress_batch.  Tuning / A-B knob only (every variant implements the same
 // contract): LZF_DECOMPRESS_KERNEL = wave (first generation, one sequence at a time) or one of the names in
 // LZF_DECOMPRESS_VARIANTS (kernels.h).  Unknown names select the default.
-enum { kVariantWave = 0, kVariantFirstBatched = 1 };
+enum { kVariantWave = 0, kVariantFirstBatched = 1, kVariantFirstWindowed = 100 };
 #define LZF_DEFAULT_VARIANT "staged16"
 int decompress_variant() {
     static const int v = [] {
@@ -50,6 +50,10 @@ int decompress_variant() {
 #define LZF_NAME(NAME, R, S_, T, ST) if (!strcmp(e, #NAME)) return id; if (!strcmp(LZF_DEFAULT_VARIANT, #NAME)) def = id; ++id;
         LZF_DECOMPRESS_VARIANTS(LZF_NAME)
 #undef LZF_NAME
+        id = kVariantFirstWindowed;
+#define LZF_NAMEW(NAME, RG, R_, W_) if (!strcmp(e, #NAME)) return id; if (!strcmp(LZF_DEFAULT_VARIANT, #NAME)) def = id; ++id;
+        LZF_WINDOWED_VARIANTS(LZF_NAMEW)
+#undef LZF_NAMEW
         return def;
     }();
     return v;
@@ -98,12 +102,33 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
     const int variant = decompress_variant();
     if (variant == kVariantWave) {
         hipLaunchKernelGGL(lzf::lzf_decompress_wave_kernel, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs);
-    } else {
+    } else if (variant < kVariantFirstWindowed) {
         int id = kVariantFirstBatched;
 #define LZF_LAUNCH(NAME, R, S_, T, ST) \
         if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<R, S_, T, ST>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs);
         LZF_DECOMPRESS_VARIANTS(LZF_LAUNCH)
 #undef LZF_LAUNCH
+    } else {
+        // windowed kernels keep each block's token list in a stream-ordered scratch area (freed when the kernels are done)
+        uint32_t stride = 0;
+        { int id = kVariantFirstWindowed;
+#define LZF_STRIDE(NAME, RG, R_, W_) if (variant == id++) stride = LZF_WINDOWED_STRIDE(R_);
+          LZF_WINDOWED_VARIANTS(LZF_STRIDE)
+#undef LZF_STRIDE
+        }
+        const uint32_t kSlice = 16384;           // jobs per launch: bounds the scratch area to ~0.4 GB
+        const uint32_t slots = n_jobs < kSlice ? n_jobs : kSlice;
+        uint16_t* scratch = nullptr;
+        HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), (size_t)slots * stride * sizeof(uint16_t), st));
+        for (uint32_t base = 0; base < n_jobs; base += kSlice) {
+            const uint32_t cnt = n_jobs - base < kSlice ? n_jobs - base : kSlice;
+            int id = kVariantFirstWindowed;
+#define LZF_LAUNCHW(NAME, RG, R_, W_) \
+            if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_windowed_kernel<RG, R_, W_>), dim3(cnt), dim3(64), 0, st, d_jobs + base, d_results + base, cnt, scratch, stride);
+            LZF_WINDOWED_VARIANTS(LZF_LAUNCHW)
+#undef LZF_LAUNCHW
+        }
+        HIP_TRY(hipFreeAsync(scratch, st));
     }
     HIP_TRY(hipGetLastError());
     return LZF_OK;

@@ -23,6 +23,23 @@ __global__ void lzf_decompress_batched_kernel(const lzf_decompress_job* __restri
 #define LZF_EXT(NAME, R, S_, T, ST) extern template __global__ void lzf_decompress_batched_kernel<R, S_, T, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
 LZF_DECOMPRESS_VARIANTS(LZF_EXT)
 #undef LZF_EXT
+// Third generation (lz4_decompress_windowed.hip): X(name, ring bytes, region bytes).  The token list of a chunk lives
+// in a scratch area of LZF_WINDOWED_STRIDE(region) u16 entries per job.
+template <int RING, int R, int WIN>
+__global__ void lzf_decompress_windowed_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results,
+                                               uint32_t n_jobs, uint16_t* __restrict__ scratch, uint32_t scratch_stride);
+#define LZF_WINDOWED_STRIDE(R_) ((((64u * (R_)) / 3u + 1u + 64u) + 63u) & ~63u)
+#define LZF_WINDOWED_VARIANTS(X) \
+    X(win256, 4096, 256, 64)   \
+    X(win512, 4096, 512, 64)   \
+    X(win1024, 4096, 1024, 64) \
+    X(win1024w, 4096, 1024, 128) \
+    X(win512w, 4096, 512, 128) \
+    X(win1024r2, 2048, 1024, 64) \
+    X(win512r8, 8192, 512, 64)
+#define LZF_EXTW(NAME, RG, R_, W_) extern template __global__ void lzf_decompress_windowed_kernel<RG, R_, W_>(const lzf_decompress_job*, lzf_job_result*, uint32_t, uint16_t*, uint32_t);
+LZF_WINDOWED_VARIANTS(LZF_EXTW)
+#undef LZF_EXTW
 template <int KIND>
 __global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
                                          lzf_job_result* __restrict__ results, uint32_t n_jobs);

@@ -36,73 +36,11 @@
 // (decompress.rs:63-75,82-89); across sequences the first one in stream order wins.
 #include "lzf_device.h"
 #include "kernels.h"
+#include "lzf_copy_helpers.h"
 
 namespace lzf {
 
 namespace {
-
-constexpr uint32_t kMaxPosB = 0x7FFFFF00u;
-constexpr uint32_t kShort = 32;          // bytes a lane moves by itself; longer runs are cooperative
-constexpr uint32_t kTotClamp = 1u << 25; // per-sequence output clamp inside the position scan
-#ifndef LZF_DBG_SKIP
-#define LZF_DBG_SKIP 0      // analysis builds only: bit0 batches, bit1 serial matches, bit2 far, bit3 literals, bit4 flush, bit5 round 1
-#endif
-
-// Exact per-lane copy of n (1..32) bytes between two non-overlapping LDS byte ranges, neither of
-// which wraps: two-ended pieces (first/last 8, 4 or 2 bytes), at most 4 reads + 4 writes.
-__device__ __forceinline__ void put_small_lds(uint32_t dst, uint32_t srca, uint32_t n) {
-    if (n >= 8u) {
-        const bool big = n > 16u;
-        uint64_t v0, v1, v2, v3;
-        lds_ld64x4(srca, big ? srca + 8u : srca, big ? srca + n - 16u : srca, srca + n - 8u, v0, v1, v2, v3);
-        lds_st64(dst, v0);
-        if (big) { lds_st64(dst + 8u, v1); lds_st64(dst + n - 16u, v2); }
-        lds_st64(dst + n - 8u, v3);
-    } else if (n >= 4u) {
-        uint32_t v0, v1; lds_ld32x2(srca, srca + n - 4u, v0, v1);
-        lds_st32(dst, v0); lds_st32(dst + n - 4u, v1);
-    } else if (n >= 2u) {
-        uint32_t v0, v1; lds_ld16x2(srca, srca + n - 2u, v0, v1);
-        lds_st16(dst, v0); lds_st16(dst + n - 2u, v1);
-    } else if (n == 1u) {
-        lds_st8(dst, lds_ld8(srca));
-    }
-}
-// A match is 4..32 bytes here: two classes only.
-__device__ __forceinline__ void put_match_lds(uint32_t dst, uint32_t srca, uint32_t n) {
-    if (n >= 8u) {
-        const bool big = n > 16u;
-        uint64_t v0, v1, v2, v3;
-        lds_ld64x4(srca, big ? srca + 8u : srca, big ? srca + n - 16u : srca, srca + n - 8u, v0, v1, v2, v3);
-        lds_st64(dst, v0);
-        if (big) { lds_st64(dst + 8u, v1); lds_st64(dst + n - 16u, v2); }
-        lds_st64(dst + n - 8u, v3);
-    } else {
-        uint32_t v0, v1; lds_ld32x2(srca, srca + n - 4u, v0, v1);
-        lds_st32(dst, v0); lds_st32(dst + n - 4u, v1);
-    }
-}
-// Same, source in global memory (unaligned loads; reads exactly [g, g+n)).
-__device__ __forceinline__ void put_small_glb(uint32_t dst, cgu8* g, uint32_t n) {
-    if (n >= 8u) {
-        const bool big = n > 16u;
-        const uint64_t v0 = ld8(g), v3 = ld8(g + n - 8u);
-        uint64_t v1 = 0, v2 = 0;
-        if (big) { v1 = ld8(g + 8u); v2 = ld8(g + n - 16u); }
-        lds_st64(dst, v0);
-        if (big) { lds_st64(dst + 8u, v1); lds_st64(dst + n - 16u, v2); }
-        lds_st64(dst + n - 8u, v3);
-    } else if (n >= 4u) {
-        const uint32_t v0 = ld4(g), v1 = ld4(g + n - 4u);
-        lds_st32(dst, v0); lds_st32(dst + n - 4u, v1);
-    } else if (n >= 2u) {
-        const uint32_t v0 = ld2(g), v1 = ld2(g + n - 2u);
-        lds_st16(dst, v0); lds_st16(dst + n - 2u, v1);
-    } else if (n == 1u) {
-        lds_st8(dst, g[0]);
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // The token-hop loop of the parse, hand-scheduled (direct variants: tokens are read from HBM/L2).
 // The scalar unit is shared by the CU's four SIMDs and is the scarce issue resource of this kernel;
@@ -252,8 +190,6 @@ __device__ __forceinline__ void lds_ld8x4(uint32_t a0, uint32_t a1, uint32_t a2,
                  : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3) : "v"(a0), "v"(a1), "v"(a2), "v"(a3) : "memory");
 }
 
-struct No { static constexpr bool value = false; };
-struct Yes { static constexpr bool value = true; };
 
 }  // namespace
 
@@ -598,293 +534,9 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
             }
             PHASE(0);
 
-            // =====================================================================
-            // B. batches of up to 64 sequences: lane j owns token tidx + j
-            // =====================================================================
-            uint32_t tidx = 0;
-            if (LZF_DBG_SKIP & 1) { tidx = Tc; o += Tc; }
-            while (tidx < Tc && status == LZF_OK) {
-                const uint32_t ob0 = o;
-                const uint32_t nb_try = Tc - tidx < kWave ? Tc - tidx : kWave;
-                const bool act0 = lane < nb_try;
-                // ---- re-read the token (decompress.rs:61-71), per lane
-                uint32_t L = 0, M = 0, src = 0;
-                bool has = false;
-                if (act0) {
-                    const uint32_t tp = cstart + toks[tidx + lane];
-                    const uint32_t w = rd4(tp);                      // token + first literal-length extension byte
-                    const uint32_t tok = w & 255u;
-                    uint32_t q = tp + 1u;
-                    L = tok >> 4;
-                    if (L == 15u) {
-                        uint32_t b = (w >> 8) & 255u; ++q;
-                        L += b;
-                        while (b == 255u) { b = rdb(q); ++q; L += b; if (L > kMaxPosB) L = kMaxPosB; }
-                    }
-                    src = q; q += L;
-                    if (len - q >= 2u) {
-                        has = true; q += 2u;
-                        M = tok & 15u;
-                        if (M == 15u) { for (;;) { const uint32_t b = rdb(q); ++q; M += b; if (M > kMaxPosB) M = kMaxPosB; if (b != 255u) break; } }
-                        M += 4u;
-                    }
-                }
-                // ---- output positions
-                uint32_t tot = L + M; if (tot > kTotClamp || tot < L) tot = kTotClamp;
-                const uint32_t incl = wave_scan_add(act0 ? tot : 0u);
-                const uint32_t lo = ob0 + (incl - (act0 ? tot : 0u));
-                const uint32_t mo = lo + L;
-                const uint32_t c = first_lane(__ballot(act0 && incl > kSpanMax));
-                const uint32_t nb = c < nb_try ? c : nb_try;       // sequences in this batch
-
-                if (nb == 0u) {
-                    // =============================================================
-                    // C. solo sequence (larger than a batch): HBM -> HBM, then re-fill the ring
-                    // =============================================================
-                    const uint32_t s_L = __builtin_amdgcn_readlane(L, 0);
-                    const uint32_t s_M = __builtin_amdgcn_readlane(M, 0);
-                    const uint32_t s_src = __builtin_amdgcn_readlane(src, 0);
-                    const bool s_has = __builtin_amdgcn_readlane((uint32_t)has, 0) != 0u;
-                    if (cap - o < s_L) { status = LZF_OUT_CAPACITY; break; }
-                    if (s_has && (uint64_t)o + s_L + s_M > limit) { status = LZF_MEMORY_LIMIT_EXCEEDED; break; }   // :72-74
-                    const uint32_t o_before = o;
-                    wave_copy(out + o, in + s_src, s_L, lane);                           // literals :65-67
-                    o += s_L;
-                    if (s_has) {
-                        const uint32_t offset = (uint32_t)in[s_src + s_L] | ((uint32_t)in[s_src + s_L + 1u] << 8);
-                        uint32_t mlen = s_M;
-                        if (offset == 0u) { status = LZF_ZERO_DEDUP_OFFSET; break; }      // :83
-                        bool done = false;
-                        if (offset > o) {                                                 // :84-99
-                            const uint32_t need = offset - o;
-                            if (need > plen) { status = LZF_INVALID_DEDUP_OFFSET; break; }
-                            const uint32_t nn = need < mlen ? need : mlen;
-                            if (cap - o < nn) { status = LZF_OUT_CAPACITY; break; }
-                            wave_copy(out + o, prefix + (plen - need), nn, lane);
-                            o += nn; mlen -= nn;
-                            done = mlen == 0u;
-                        }
-                        if (!done) {
-                            if (cap - o < mlen) { status = LZF_OUT_CAPACITY; break; }
-                            const uint32_t src0 = o - offset;
-                            const uint32_t span = mlen < offset ? mlen : offset;
-                            if (src0 + span > safe) { wave_store_fence(); safe = o; }
-                            cgu8* hist = out + src0;
-                            gu8* dst = out + o;
-                            if (mlen <= offset) {
-                                wave_copy(dst, hist, mlen, lane);
-                            } else if (offset == 1u) {
-                                const uint32_t b = hist[0];
-                                const uint32_t b4 = b * 0x01010101u;
-                                const u32x4 v = {b4, b4, b4, b4};
-                                const uint32_t bulk = mlen & ~15u;
-                                for (uint32_t i = lane * 16u; i < bulk; i += kWave * 16u) st16(dst + i, v);
-                                if (lane < mlen - bulk) dst[bulk + lane] = (uint8_t)b;
-                            } else {
-                                uint32_t r = lane % offset;
-                                const uint32_t adv = kWave % offset;
-                                for (uint32_t i = lane; i < mlen; i += kWave) {
-                                    dst[i] = hist[r];
-                                    r += adv; if (r >= offset) r -= offset;
-                                }
-                            }
-                            o += mlen;
-                        }
-                    }
-                    // ring <- the tail of what was just written
-                    wave_store_fence(); safe = o;
-                    ring_fill((o - o_before > (uint32_t)RING) ? o - RING : o_before, o);
-                    tidx += 1u;
-                    continue;
-                }
-
-                const bool act = lane < nb;
-                has = has && act;
-                if (!act) { L = 0; M = 0; }
-                uint32_t off = 0;
-                if (has) { if (STAGE) off = rdb(src + L) | (rdb(src + L + 1u) << 8); else off = ld2(in + src + L); }
-                // ---- errors, first sequence in stream order wins; inside a sequence the reference's order
-                int code = LZF_OK;
-                if (act) {
-                    if (lo > cap || cap - lo < L) code = LZF_OUT_CAPACITY;                        // our buffer (literals)
-                    else if (has && (uint64_t)mo + M > limit) code = LZF_MEMORY_LIMIT_EXCEEDED;    // :72-74
-                    else if (has && off == 0u) code = LZF_ZERO_DEDUP_OFFSET;                       // :83
-                    else if (has && off > mo && off - mo > plen) code = LZF_INVALID_DEDUP_OFFSET;  // :84-89
-                    else if (has && cap - mo < M) code = LZF_OUT_CAPACITY;                         // our buffer (match)
-                }
-                const uint32_t e = first_lane(__ballot(code != LZF_OK));
-                if (e < 64u) { status = __builtin_amdgcn_readlane(code, e); break; }
-                PHASE(1);
-
-                // ---- matches (copy_overlapping, decompress.rs:80-138)
-                const uint32_t near_lo = ob0 > kNearHist ? ob0 - kNearHist : 0u;
-                const uint32_t span = M < off ? M : off;                  // distinct source bytes
-                const bool from_prefix = has && off > mo;
-                const uint32_t s0 = mo - off;                             // valid when !from_prefix
-                const bool is_near = has && !from_prefix && s0 >= near_lo;
-                const bool is_far = has && !from_prefix && s0 + span <= near_lo;
-                const bool is_slow = has && !is_near && !is_far;          // prefix or straddling
-                const uint32_t mi = RIDX(mo);
-                const bool mwrap = mi + M > (uint32_t)RING;               // destination wraps around the ring
-                // HBM visibility of what far / slow lanes read back
-                {
-                    uint32_t need = 0;
-                    if (is_far) need = s0 + M;
-                    if (is_slow && !from_prefix) need = near_lo;
-                    if (is_slow && from_prefix && M > off - mo) need = near_lo;
-                    if (need > ob0) need = ob0;
-                    if (__ballot(need > safe)) { wave_store_fence(); safe = ob0; }
-                }
-                // far (never overlapping: offset > ring history > length): HBM -> ring.  The loads of the short
-                // ones are issued here and land while the literals are being copied; the stores follow below.
-                const bool far_own = !(LZF_DBG_SKIP & 4) && is_far && M <= kShort && !mwrap;
-                uint64_t fv0 = 0, fv1 = 0, fv2 = 0, fv3 = 0;
-                if (far_own) {
-                    cgu8* g = out + s0;
-                    if (M >= 8u) {
-                        fv0 = ld8(g); fv3 = ld8(g + M - 8u);
-                        if (M > 16u) { fv1 = ld8(g + 8u); fv2 = ld8(g + M - 16u); }
-                    } else {
-                        fv0 = ld4(g); fv3 = ld4(g + M - 4u);
-                    }
-                }
-                // ---- literals -> ring (decompress.rs:65-67)
-                if (!(LZF_DBG_SKIP & 8) && __ballot(L > 0u)) {
-                    const uint32_t n1 = L < kShort ? L : kShort;            // the lane's own share
-                    const uint32_t ri = RIDX(lo);
-                    if (n1 > 0u) {
-                        if (ri + n1 > (uint32_t)RING) {                     // wraps around the ring: bytes
-                            for (uint32_t t = 0; t < n1; ++t) ring[RIDX(lo + t)] = (uint8_t)rdb(src + t);
-                        } else if (STAGE && src - cstart + n1 <= kCB) {
-                            put_small_lds(ring_a + ri, cbuf_a + (src - cstart), n1);
-                        } else {
-                            put_small_glb(ring_a + ri, in + src, n1);
-                        }
-                    }
-                    for (unsigned long long m = __ballot(L > kShort); m; m &= m - 1ull) {      // long runs: all lanes
-                        const uint32_t j = (uint32_t)__builtin_ctzll(m);
-                        const uint32_t jl = __builtin_amdgcn_readlane(L, j);
-                        const uint32_t js = __builtin_amdgcn_readlane(src, j);
-                        const uint32_t jo = __builtin_amdgcn_readlane(lo, j);
-                        for (uint32_t i = kShort + lane; i < jl; i += 4u * kWave) {
-                            const uint32_t i1 = i + kWave, i2 = i + 2u * kWave, i3 = i + 3u * kWave;
-                            const uint8_t b0 = in[js + i];
-                            const uint8_t b1 = i1 < jl ? in[js + i1] : (uint8_t)0;
-                            const uint8_t b2 = i2 < jl ? in[js + i2] : (uint8_t)0;
-                            const uint8_t b3 = i3 < jl ? in[js + i3] : (uint8_t)0;
-                            ring[RIDX(jo + i)] = b0;
-                            if (i1 < jl) ring[RIDX(jo + i1)] = b1;
-                            if (i2 < jl) ring[RIDX(jo + i2)] = b2;
-                            if (i3 < jl) ring[RIDX(jo + i3)] = b3;
-                        }
-                    }
-                }
-                PHASE(2);
-
-                if (far_own) {
-                    const uint32_t dsta = ring_a + mi;
-                    if (M >= 8u) {
-                        lds_st64(dsta, fv0);
-                        if (M > 16u) { lds_st64(dsta + 8u, fv1); lds_st64(dsta + M - 16u, fv2); }
-                        lds_st64(dsta + M - 8u, fv3);
-                    } else {
-                        lds_st32(dsta, (uint32_t)fv0); lds_st32(dsta + M - 4u, (uint32_t)fv3);
-                    }
-                }
-                if (!(LZF_DBG_SKIP & 4) && __ballot(is_far && !far_own)) {
-                    if (is_far && M <= kShort && mwrap) { for (uint32_t t = 0; t < M; ++t) ring[RIDX(mo + t)] = out[s0 + t]; }
-                    for (unsigned long long m = __ballot(is_far && M > kShort); m; m &= m - 1ull) {
-                        const uint32_t j = (uint32_t)__builtin_ctzll(m);
-                        const uint32_t jm = __builtin_amdgcn_readlane(M, j);
-                        const uint32_t js = __builtin_amdgcn_readlane(s0, j);
-                        const uint32_t jo = __builtin_amdgcn_readlane(mo, j);
-                        for (uint32_t i = lane; i < jm; i += 4u * kWave) {
-                            const uint32_t i1 = i + kWave, i2 = i + 2u * kWave, i3 = i + 3u * kWave;
-                            const uint8_t b0 = out[js + i];
-                            const uint8_t b1 = i1 < jm ? out[js + i1] : (uint8_t)0;
-                            const uint8_t b2 = i2 < jm ? out[js + i2] : (uint8_t)0;
-                            const uint8_t b3 = i3 < jm ? out[js + i3] : (uint8_t)0;
-                            ring[RIDX(jo + i)] = b0;
-                            if (i1 < jm) ring[RIDX(jo + i1)] = b1;
-                            if (i2 < jm) ring[RIDX(jo + i2)] = b2;
-                            if (i3 < jm) ring[RIDX(jo + i3)] = b3;
-                        }
-                    }
-                }
-                PHASE(3);
-                unsigned long long unresolved = __ballot(is_near || is_slow);
-                const unsigned long long slow_mask = __ballot(is_slow);
-                // Rounds in stream order.  H = start of the first unresolved match: every output byte below H is
-                // final, so each round moves, all lanes at once, every short non-overlapping near match whose
-                // source ends at or below H (on typical data most matches go in the first round; ~6 rounds per
-                // batch on the Silesia stand-in).  When the first unresolved match is not of that kind (long,
-                // overlapping, wrapping, prefix / straddling source) the wave moves that one cooperatively.
-                // LDS runs one wave's accesses in order, so no wait separates dependent rounds.
-                {
-                    const uint32_t si = RIDX(s0);
-                    const bool solo_ok = is_near && M <= off && M <= kShort && !mwrap && !(si + M > (uint32_t)RING);
-                    const unsigned long long solo_mask = __ballot(solo_ok);
-                    const uint32_t src_end = s0 + span;
-                    if (LZF_DBG_SKIP & 2) unresolved = 0;
-                    while (unresolved) {
-                        const uint32_t f = (uint32_t)__builtin_ctzll(unresolved);
-                        const unsigned long long bit = 1ull << f;
-                        if (solo_mask & bit) {
-                            const uint32_t H = __builtin_amdgcn_readlane(mo, f);
-                            const unsigned long long go = __ballot(solo_ok && src_end <= H) & unresolved;   // includes lane f
-                            if ((go >> lane) & 1ull) put_match_lds(ring_a + mi, ring_a + si, M);
-                            unresolved &= ~go;
-                            continue;
-                        }
-                        unresolved &= ~bit;
-                        if (slow_mask & bit) {
-                            // prefix / straddling source: one lane, byte-serial, three sources
-                            if (lane == f) {
-                                for (uint32_t t = 0; t < M; ++t) {
-                                    uint8_t v;
-                                    if (off > mo + t) v = prefix[plen - (off - mo) + t];                // :91-93
-                                    else {
-                                        const uint32_t s = mo + t - off;
-                                        v = s < near_lo ? out[s] : ring[RIDX(s)];
-                                    }
-                                    ring[RIDX(mo + t)] = v;
-                                }
-                            }
-                            continue;
-                        }
-                        const uint32_t jm = __builtin_amdgcn_readlane(M, f);
-                        const uint32_t js = __builtin_amdgcn_readlane(s0, f);
-                        const uint32_t jo = __builtin_amdgcn_readlane(mo, f);
-                        const uint32_t joff = __builtin_amdgcn_readlane(off, f);
-                        if (jm <= joff) {                                   // non-overlapping: 4 bytes in flight per lane
-                            for (uint32_t i = lane; i < jm; i += 4u * kWave) {
-                                const uint32_t i1 = i + kWave, i2 = i + 2u * kWave, i3 = i + 3u * kWave;
-                                const uint8_t b0 = ring[RIDX(js + i)];
-                                const uint8_t b1 = i1 < jm ? ring[RIDX(js + i1)] : (uint8_t)0;
-                                const uint8_t b2 = i2 < jm ? ring[RIDX(js + i2)] : (uint8_t)0;
-                                const uint8_t b3 = i3 < jm ? ring[RIDX(js + i3)] : (uint8_t)0;
-                                ring[RIDX(jo + i)] = b0;
-                                if (i1 < jm) ring[RIDX(jo + i1)] = b1;
-                                if (i2 < jm) ring[RIDX(jo + i2)] = b2;
-                                if (i3 < jm) ring[RIDX(jo + i3)] = b3;
-                            }
-                        } else {                                            // overlapping: period-`offset` addressing
-                            uint32_t rr = lane % joff;
-                            const uint32_t adv = kWave % joff;
-                            for (uint32_t i = lane; i < jm; i += kWave) {
-                                ring[RIDX(jo + i)] = ring[RIDX(js + rr)];
-                                rr += adv; if (rr >= joff) rr -= joff;
-                            }
-                        }
-                    }
-                }
-                PHASE(4);
-                // ---- flush the batch ring -> HBM
-                o = ob0 + __builtin_amdgcn_readlane(incl, (nb - 1u) & 63u);
-                if (!(LZF_DBG_SKIP & 16)) ring_flush(ob0, o);
-                tidx += nb;
-                PHASE(5);
-            }
+#define LZF_TOKEN_AT(i) toks[(i)]
+#include "lz4_decompress_batch_phase.inc"
+#undef LZF_TOKEN_AT
             if (status == LZF_OK && cerr != LZF_OK) status = cerr;
             cstart = cend;
         }

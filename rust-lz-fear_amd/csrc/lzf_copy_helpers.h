@@ -1,0 +1,73 @@
+// lzf_copy_helpers.h — constants and per-lane copy helpers shared by the batched decompress kernels.
+#pragma once
+#include "lzf_device.h"
+
+namespace lzf {
+namespace {
+
+constexpr uint32_t kMaxPosB = 0x7FFFFF00u;
+constexpr uint32_t kShort = 32;          // bytes a lane moves by itself; longer runs are cooperative
+constexpr uint32_t kTotClamp = 1u << 25; // per-sequence output clamp inside the position scan
+#ifndef LZF_DBG_SKIP
+#define LZF_DBG_SKIP 0      // analysis builds only: bit0 batches, bit1 serial matches, bit2 far, bit3 literals, bit4 flush, bit5 round 1
+#endif
+
+// Exact per-lane copy of n (1..32) bytes between two non-overlapping LDS byte ranges, neither of
+// which wraps: two-ended pieces (first/last 8, 4 or 2 bytes), at most 4 reads + 4 writes.
+__device__ __forceinline__ void put_small_lds(uint32_t dst, uint32_t srca, uint32_t n) {
+    if (n >= 8u) {
+        const bool big = n > 16u;
+        uint64_t v0, v1, v2, v3;
+        lds_ld64x4(srca, big ? srca + 8u : srca, big ? srca + n - 16u : srca, srca + n - 8u, v0, v1, v2, v3);
+        lds_st64(dst, v0);
+        if (big) { lds_st64(dst + 8u, v1); lds_st64(dst + n - 16u, v2); }
+        lds_st64(dst + n - 8u, v3);
+    } else if (n >= 4u) {
+        uint32_t v0, v1; lds_ld32x2(srca, srca + n - 4u, v0, v1);
+        lds_st32(dst, v0); lds_st32(dst + n - 4u, v1);
+    } else if (n >= 2u) {
+        uint32_t v0, v1; lds_ld16x2(srca, srca + n - 2u, v0, v1);
+        lds_st16(dst, v0); lds_st16(dst + n - 2u, v1);
+    } else if (n == 1u) {
+        lds_st8(dst, lds_ld8(srca));
+    }
+}
+// A match is 4..32 bytes here: two classes only.
+__device__ __forceinline__ void put_match_lds(uint32_t dst, uint32_t srca, uint32_t n) {
+    if (n >= 8u) {
+        const bool big = n > 16u;
+        uint64_t v0, v1, v2, v3;
+        lds_ld64x4(srca, big ? srca + 8u : srca, big ? srca + n - 16u : srca, srca + n - 8u, v0, v1, v2, v3);
+        lds_st64(dst, v0);
+        if (big) { lds_st64(dst + 8u, v1); lds_st64(dst + n - 16u, v2); }
+        lds_st64(dst + n - 8u, v3);
+    } else {
+        uint32_t v0, v1; lds_ld32x2(srca, srca + n - 4u, v0, v1);
+        lds_st32(dst, v0); lds_st32(dst + n - 4u, v1);
+    }
+}
+// Same, source in global memory (unaligned loads; reads exactly [g, g+n)).
+__device__ __forceinline__ void put_small_glb(uint32_t dst, cgu8* g, uint32_t n) {
+    if (n >= 8u) {
+        const bool big = n > 16u;
+        const uint64_t v0 = ld8(g), v3 = ld8(g + n - 8u);
+        uint64_t v1 = 0, v2 = 0;
+        if (big) { v1 = ld8(g + 8u); v2 = ld8(g + n - 16u); }
+        lds_st64(dst, v0);
+        if (big) { lds_st64(dst + 8u, v1); lds_st64(dst + n - 16u, v2); }
+        lds_st64(dst + n - 8u, v3);
+    } else if (n >= 4u) {
+        const uint32_t v0 = ld4(g), v1 = ld4(g + n - 4u);
+        lds_st32(dst, v0); lds_st32(dst + n - 4u, v1);
+    } else if (n >= 2u) {
+        const uint32_t v0 = ld2(g), v1 = ld2(g + n - 2u);
+        lds_st16(dst, v0); lds_st16(dst + n - 2u, v1);
+    } else if (n == 1u) {
+        lds_st8(dst, g[0]);
+    }
+}
+
+struct No { static constexpr bool value = false; };
+struct Yes { static constexpr bool value = true; };
+}  // namespace
+}  // namespace lzf
