@@ -74,6 +74,10 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
     const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs) {
     using TT = TableTraits<KIND>;
     __shared__ uint32_t tab[TT::kSlots];
+#ifdef LZF_DBG_LDS_PAD
+    __shared__ uint32_t dbg_pad[LZF_DBG_LDS_PAD / 4];     // occupancy experiment
+    if (threadIdx.x == 999) dbg_pad[0] = 1;
+#endif
 
     const uint32_t jid = blockIdx.x;
     if (jid >= n_jobs) return;
@@ -318,7 +322,20 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
             }
             cursor = m_pos + m;                                            // :215
             CPHASE(1);
-            // request the next run's first probes now; they land while this sequence is emitted
+            // The literal run is loaded first and the next run's first probes are requested right behind it, so
+            // both travel in one round trip (loads return in order: storing the literals then waits for the
+            // literal loads only, and the probes land while this sequence is emitted).
+            const uint32_t lit_len = (m_pos - bt) - ls;                    // = L below
+            const bool lit_fast = lit_len <= 1024u;
+            uint32_t lit_b = 0, lit_t = 0; u32x4 lit_v = {0, 0, 0, 0};
+            if (lit_fast) {
+                if (lit_len <= kWave) { if (lane < lit_len) lit_b = in[ls + lane]; }
+                else {
+                    const uint32_t bulk = lit_len & ~15u;
+                    if (lane * 16u < bulk) lit_v = ld16(in + ls + lane * 16u);
+                    if (lane < lit_len - bulk) lit_t = in[ls + bulk + lane];
+                }
+            }
             {
                 const uint32_t ckn = cursor + lane;
                 pfA0 = 0; pfA1 = 0;
@@ -360,7 +377,17 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                 d[2u + nl + L] = (uint8_t)(dup_offset >> 8);
             }
             if (nl) lsic_store(d + 1, L, nl, lane);
-            wave_copy(d + 1u + nl, in + ls, L, lane);
+            if (lit_fast) {
+                gu8* ld = d + 1u + nl;
+                if (L <= kWave) { if (lane < L) ld[lane] = (uint8_t)lit_b; }
+                else {
+                    const uint32_t bulk = L & ~15u;
+                    if (lane * 16u < bulk) st16(ld + lane * 16u, lit_v);
+                    if (lane < L - bulk) ld[bulk + lane] = (uint8_t)lit_t;
+                }
+            } else {
+                wave_copy(d + 1u + nl, in + ls, L, lane);
+            }
             if (ne) lsic_store(d + 3u + nl + L, extra, ne, lane);
             s.pos += total;
             CPHASE(3);

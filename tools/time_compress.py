@@ -1,0 +1,24 @@
+"""Time one compress launch over `copies` x the Silesia stand-in (analysis).  usage: python tools/time_compress.py [copies] [reps]"""
+import sys, os, time, numpy as np, torch
+sys.path.insert(0, os.getcwd())
+import rust_lz_fear_amd
+from rust_lz_fear_amd import device, synth
+copies = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+BS = 4 << 20
+data = synth.silesia_mix()
+d_in = torch.from_numpy(data).cuda()
+blocks = device.BlockSet(d_in, BS); n = blocks.n
+j1 = blocks.compress_jobs(torch.empty(1, dtype=torch.uint8, device='cuda'), BS)
+m = n * copies
+d_out = torch.empty(m * BS, dtype=torch.uint8, device='cuda')
+cj = np.tile(j1, copies)
+cj['out'] = d_out.data_ptr() + np.arange(m, dtype=np.uint64) * BS
+d_cj = device.to_device(cj, 'cuda'); d_res = torch.zeros(m * 16, dtype=torch.uint8, device='cuda')
+for it in range(reps):
+    torch.cuda.synchronize(); t = time.time()
+    device.compress_batch(d_cj, d_res, m); torch.cuda.synchronize()
+    dt = time.time() - t
+    print(f"jobs {m} raw {len(data)*copies} time {dt*1e3:.1f} ms  {len(data)*copies/dt/2**30:.2f} GiB/s", flush=True)
+res = device.results_to_host(d_res, m)
+print("status counts", np.unique(res['status'], return_counts=True), "sum out_len", int(res['out_len'][res['status']==0].sum()))
