@@ -85,10 +85,15 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
     if (rc < 0) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     if (table_kinds == 0) table_kinds = LZF_KINDS_U32 | LZF_KINDS_U16;
-    if (table_kinds & LZF_KINDS_U32)
-        hipLaunchKernelGGL(lzf::lzf_compress_wave_kernel<LZF_TABLE_U32>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs);
+    // U32 jobs with a fresh or read-only template table go to the compact-table kernel (18 instead of 10 waves per CU);
+    // LZF_COMPRESS_KERNEL=general keeps everything on the general kernel (A/B knob, same output).
+    static const uint32_t use_compact = [] { const char* e = getenv("LZF_COMPRESS_KERNEL"); return (e && !strcmp(e, "general")) ? 0u : 1u; }();
+    if (table_kinds & LZF_KINDS_U32) {
+        if (use_compact) hipLaunchKernelGGL(lzf::lzf_compress_compact_kernel, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs);
+        hipLaunchKernelGGL(lzf::lzf_compress_wave_kernel<LZF_TABLE_U32>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, use_compact);
+    }
     if (table_kinds & LZF_KINDS_U16)
-        hipLaunchKernelGGL(lzf::lzf_compress_wave_kernel<LZF_TABLE_U16>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs);
+        hipLaunchKernelGGL(lzf::lzf_compress_wave_kernel<LZF_TABLE_U16>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, 0u);
     HIP_TRY(hipGetLastError());
     return LZF_OK;
 }

@@ -42,9 +42,11 @@ LZF_WINDOWED_VARIANTS(LZF_EXTW)
 #undef LZF_EXTW
 template <int KIND>
 __global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
-                                         lzf_job_result* __restrict__ results, uint32_t n_jobs);
-extern template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U32>(const lzf_compress_job*, lzf_job_result*, uint32_t);
-extern template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U16>(const lzf_compress_job*, lzf_job_result*, uint32_t);
+                                         lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t skip_compact);
+extern template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U32>(const lzf_compress_job*, lzf_job_result*, uint32_t, uint32_t);
+extern template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U16>(const lzf_compress_job*, lzf_job_result*, uint32_t, uint32_t);
+__global__ void lzf_compress_compact_kernel(const lzf_compress_job* __restrict__ jobs,
+                                            lzf_job_result* __restrict__ results, uint32_t n_jobs);
 __global__ void lzf_xxh32_kernel(const uint8_t* const* __restrict__ ptrs, const uint64_t* __restrict__ lens,
                                  uint32_t* __restrict__ out, uint32_t n);
 __global__ void lzf_seed_table_kernel(lzf_u32_table* __restrict__ t, const uint8_t* __restrict__ dict, uint64_t dict_len);

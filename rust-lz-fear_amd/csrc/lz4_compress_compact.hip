@@ -1,96 +1,92 @@
-// lz4_compress.hip — batched raw::compress2 for gfx950 (MI355X), wave64, bit-exact.
+// lz4_compress_compact.hip — raw::compress2 with U32Table semantics for gfx950, compact position table.
 //
-// Replaces src/raw/compress/mod.rs:165-238 of lz-fear (compress2) together with its tables
-// (:27-101), count_matching_bytes (:117-145) and write_group / LSIC coding (:150-163,:239-260)
-// for many blocks per launch.  One wavefront compresses one block; the position table lives
-// in LDS (16 KiB for U32Table, 32 KiB for the U16Table variant).
-//
-// The reference parse is a strictly sequential state machine (greedy first match, single-slot
-// table, skip schedule); its output depends on the exact order of table updates.  The kernel
-// reproduces it with *speculative batches*: the 64 lanes evaluate the next 64 probe positions
-// of the skip schedule (closed form below) as if every earlier probe in the batch missed, and
-// the wave then commits exactly the prefix the sequential algorithm would have executed:
-//   1. lane k hashes input[c_k..c_k+8) and reads its table slot (the pre-batch value);
-//   2. same-slot collisions inside the batch are found by a min-lane tag written through the
-//      slot itself (ds_write MARK, ds_min lane, ds_read): lane k is "first" for its slot iff
-//      the tag equals k.  The batch is cut after the first lane D that is not first — its
-//      candidate is the position of the (unique) earlier lane with the same slot;
-//   3. the winner W is the first lane whose candidate passes the reference's accept test
-//      (mod.rs:200-206), or the first lane that hits the <12-bytes-left rule (:178);
-//   4. lanes <= W write their positions (the sequential `replace` calls that really happened),
-//      every other touched slot gets its pre-batch value back.
-// Match extension and backtracking (:204,:211-212) are wave-parallel compares + ballot.
+// Same algorithm, same speculative batches and the same output as lz4_compress.hip (see there for the
+// description and the reference lines); the difference is the table.  The compress kernel is latency-
+// bound (two dependent HBM/MALL round trips per sequence) and its throughput is proportional to the
+// wavefronts a CU holds, which the 16 KiB of LDS a 4096 x u32 table needs caps at 10.  Here a slot keeps
+// only the low 16 bits of the position; one more bit per slot (par[]) holds the parity of the position's
+// 64 KiB epoch.  A candidate is acceptable only within 65535 bytes (mod.rs:201), i.e. in the current or the
+// previous epoch, so those 17 bits identify it exactly — provided no entry older than that survives:
+// whenever the cursor enters a new epoch E every slot whose parity equals E's (all of them from epoch
+// E-2 or older) is cleared to "position (E-1) << 16", which is out of reach for the whole of epoch E
+// (sweep_to; ~250 instructions per 64 KiB of input).  A batch never straddles an epoch boundary.
+// The min-lane tag that finds same-slot collisions inside a batch goes through the 32-bit LDS word that
+// holds two slots; the batch is cut at the first lane whose word is shared, which is either the collision
+// the sequential algorithm would see (same slot) or a neighbour (then nothing happens: the cut lane is
+// evaluated normally and the next batch starts behind it).  8.5 KiB of LDS per wave: 18 waves per CU.
+// Jobs with a caller-owned writable table, a table offset or U16Table semantics stay on the general kernel
+// (compress_job_is_compact, lzf_compress_common.h).
 #include "lzf_device.h"
 #include "lzf_compress_common.h"
+#include "kernels.h"
 
 namespace lzf {
 
-template <int KIND> struct TableTraits;
-template <> struct TableTraits<LZF_TABLE_U32> {
-    static constexpr uint32_t kSlots = 4096;
-    static constexpr uint64_t kLimit = 0xFFFFFFFFull;                 // mod.rs:75
-    // mod.rs:41-51: v = 8 bytes LE (0 if fewer than 8 remain), ((v << 24) * 889523592379) >> 52
-    static __device__ __forceinline__ uint32_t hash(uint64_t v8) {
-        return (uint32_t)(((v8 << 24) * 889523592379ull) >> 52);
-    }
-};
-template <> struct TableTraits<LZF_TABLE_U16> {
-    static constexpr uint32_t kSlots = 8192;
-    static constexpr uint64_t kLimit = 0xFFFFull;                     // mod.rs:100
-    // mod.rs:58-61: (u32 * 2654435761) >> 19
-    static __device__ __forceinline__ uint32_t hash(uint64_t v8) {
-        return ((uint32_t)v8 * 2654435761u) >> 19;
-    }
-};
+namespace {
+constexpr uint32_t kSlots = 4096;
+// mod.rs:41-51: v = 8 bytes LE (0 if fewer than 8 remain), ((v << 24) * 889523592379) >> 52
+__device__ __forceinline__ uint32_t hash5(uint64_t v8) { return (uint32_t)(((v8 << 24) * 889523592379ull) >> 52); }
+}  // namespace
 
-template <int KIND>
-__global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
-    const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t skip_compact) {
-    using TT = TableTraits<KIND>;
-    __shared__ uint32_t tab[TT::kSlots];
-#ifdef LZF_DBG_LDS_PAD
-    __shared__ uint32_t dbg_pad[LZF_DBG_LDS_PAD / 4];     // occupancy experiment
-    if (threadIdx.x == 999) dbg_pad[0] = 1;
-#endif
+__global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
+    const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs) {
+    __shared__ __attribute__((aligned(16))) uint32_t tab32[kSlots / 2];   // slot h = 16-bit half (h & 1) of word h >> 1
+    __shared__ uint32_t par[kSlots / 32];                                 // epoch parity of slot h = bit (h & 31) of word h >> 5
+    uint16_t* const tab16 = reinterpret_cast<uint16_t*>(tab32);
 
     const uint32_t jid = blockIdx.x;
     if (jid >= n_jobs) return;
     const uint32_t lane = threadIdx.x;
     const lzf_compress_job job = jobs[jid];
     const long long t_start = clock64();
-    if (job.table_kind != (uint32_t)KIND) return;   // handled by the other instantiation
-    if (skip_compact && compress_job_is_compact(job)) return;   // handled by lzf_compress_compact_kernel
+    if (!compress_job_is_compact(job)) return;      // handled by lzf_compress_wave_kernel
 
     cgu8* __restrict__ in = as_global(job.input);
     int status = LZF_OK;
-#ifdef LZF_PHASE_TIMING
-    long long g_tph[4] = {0, 0, 0, 0};
-#endif
     Sink s{as_global(job.out), 0u, job.out_cap > kMaxLen ? kMaxLen : (uint32_t)job.out_cap};
-    uint64_t base_off = 0;   // EncoderTable.offset (mod.rs:30,:81)
-
-    // ---- table in: Default::default() (:32-36) or the caller's table
-    if (job.table) {
-        if (KIND == LZF_TABLE_U32) {
-            const LZF_GLOBAL lzf_u32_table* t = (const LZF_GLOBAL lzf_u32_table*)job.table;
-            for (uint32_t i = lane; i < TT::kSlots; i += kWave) tab[i] = t->dict[i];
-            base_off = t->offset;
-        } else {
-            const LZF_GLOBAL lzf_u16_table* t = (const LZF_GLOBAL lzf_u16_table*)job.table;
-            for (uint32_t i = lane; i < TT::kSlots; i += kWave) tab[i] = t->dict[i];
-            base_off = t->offset;
-        }
-    } else {
-        for (uint32_t i = lane; i < TT::kSlots; i += kWave) tab[i] = 0u;
-    }
-
-    if (job.input_len > TT::kLimit || job.input_len >= kMaxLen || job.cursor > job.input_len) {
-        status = LZF_CONTRACT;                                           // mod.rs:167
-    } else {
+    {
         const uint32_t len = (uint32_t)job.input_len;
         const uint32_t init = (uint32_t)job.cursor;                      // :169
         uint32_t cursor = init;
-        const uint32_t boff = (uint32_t)base_off;   // low 32 bits; overflow is checked at commit
+        uint32_t swept = init >> 16;                                     // epoch the table is consistent with
+        // ---- table in: Default::default() (:32-36) or the caller's read-only template, converted
+        {
+            const uint32_t e0 = swept;
+            const uint32_t gone_par = e0 >= 1u ? (e0 - 1u) & 1u : 0u;    // parity that marks "out of reach" in epoch e0
+            if (job.table) {
+                const LZF_GLOBAL lzf_u32_table* t = (const LZF_GLOBAL lzf_u32_table*)job.table;
+                for (uint32_t i = lane; i < kSlots; i += kWave) {
+                    const uint32_t v = t->dict[i];
+                    const uint32_t e = v >> 16;
+                    const bool keep = e == e0 || e + 1u == e0;             // within reach of the first probes
+                    tab16[i] = keep ? (uint16_t)v : (uint16_t)0;
+                    const unsigned long long bm = __ballot(keep ? (e & 1u) != 0u : gone_par != 0u);
+                    if (lane == 0) { par[i >> 5] = (uint32_t)bm; par[(i >> 5) + 1u] = (uint32_t)(bm >> 32); }
+                }
+            } else {
+                for (uint32_t i = lane; i < kSlots / 2; i += kWave) tab32[i] = 0u;
+                for (uint32_t i = lane; i < kSlots / 32; i += kWave) par[i] = gone_par ? 0xFFFFFFFFu : 0u;
+            }
+        }
+        // The cursor enters epoch E (> swept): entries of epoch E-2 and older go out of reach.
+        auto sweep_to = [&](uint32_t E) {
+            const uint32_t keep_par = (E - 1u) & 1u;
+            if (E == swept + 1u) {
+                for (uint32_t w = lane; w < kSlots / 32; w += kWave) {
+                    const uint32_t pw = par[w];
+                    const uint32_t del = keep_par ? ~pw : pw;            // slots whose parity is E's
+                    for (uint32_t t = 0; t < 16u; ++t) {
+                        const uint32_t two = (del >> (2u * t)) & 3u;
+                        if (two) tab32[w * 16u + t] &= ((two & 1u) ? 0u : 0xFFFFu) | ((two & 2u) ? 0u : 0xFFFF0000u);
+                    }
+                    par[w] = keep_par ? 0xFFFFFFFFu : 0u;
+                }
+            } else {                                                     // a long match skipped an epoch: nothing is in reach
+                for (uint32_t i = lane; i < kSlots / 2; i += kWave) tab32[i] = 0u;
+                for (uint32_t i = lane; i < kSlots / 32; i += kWave) par[i] = keep_par ? 0xFFFFFFFFu : 0u;
+            }
+            swept = E;
+        };
 
         // 8 input bytes at pos; bytes at or beyond len read as 0
         auto ld8_part = [&](uint32_t pos) -> uint64_t {
@@ -103,12 +99,7 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
         // as soon as the cursor is known (before the previous sequence is emitted) and consumed here.
         uint32_t pf_c = 0xFFFFFFFFu;
         uint64_t pfA0 = 0, pfA1 = 0;
-#ifdef LZF_PHASE_TIMING
-        long long tq = clock64();
-#define CPHASE(i) do { const long long tn = clock64(); g_tph[i] += tn - tq; tq = tn; } while (0)
-#else
 #define CPHASE(i) do { } while (0)
-#endif
 
         while (cursor < len && status == LZF_OK) {                        // :171
             const uint32_t ls = cursor;                                   // :172 literal_start
@@ -121,11 +112,12 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
 
             // ================= search: speculative batches of the :177-232 loop
             for (;;) {
+                { const uint32_t eb = c >> 16; if (eb != swept) sweep_to(eb); }        // the batch base enters a new 64 KiB epoch
                 // Common case, decided once per batch with scalar compares: first batch of a run, not at
                 // the block's edges.  Then every lane is a plain probe (no schedule arithmetic, no end-of-
                 // input lanes, full 16-byte loads in range, positions fit the slot type).
                 const bool easy = n == 0u && c > init && c >= 8u && (uint64_t)c + kFirstBatch + 40u <= len &&
-                                  (uint64_t)c + kFirstBatch + base_off <= TT::kLimit;
+                                  ((c + kFirstBatch - 1u) >> 16) == (c >> 16);          // and the batch stays inside one epoch
                 // probe positions: the first 66 probes of a run advance by 1 (mod.rs:225-231)
                 uint32_t ck, sn = 0;
                 if (n + 64u <= 66u) ck = c + lane;
@@ -136,35 +128,50 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                 const uint32_t bw = n == 0u ? kFirstBatch : kWave;
                 const bool inb = lane < bw;
                 const bool endk = easy ? false : (inb && ((ck > len) || (len - ck < 12u)));   // :178
-                const bool active = inb && !endk;
+                const bool epk = easy ? false : (inb && (ck >> 16) != (c >> 16));     // beyond the epoch of the batch base: next batch
+                const bool active = inb && !endk && !epk;
                 uint64_t A0 = 0, A1 = 0;                                  // input[ck .. ck+16)
                 if (n == 0u && pf_c == c) { A0 = pfA0; A1 = pfA1; }
                 else if (easy) { if (inb) { A0 = ld8(in + ck); A1 = ld8(in + ck + 8u); } }
                 else if (active) { A0 = ld8(in + ck); A1 = ld8_part(ck + 8u); }   // >= 12 bytes remain
                 pf_c = 0xFFFFFFFFu;
-                const uint32_t h = TT::hash(A0);
-                uint32_t old = 0, first = lane;
-                if (active) old = tab[h];
-                if (active) tab[h] = kMark;
-                if (active) atomicMin(&tab[h], lane);
-                if (active) first = tab[h];
-                const bool dup = active && first != lane;
-                const uint32_t D = first_lane(__ballot(dup));             // 64 = no collision
+                const uint32_t h = hash5(A0);
+                const uint32_t wi = h >> 1;                               // two 16-bit slots per LDS word
+                uint32_t oldpair = 0, pw = 0, first = lane;
+                if (active) oldpair = tab32[wi];
+                if (active) pw = par[h >> 5];
+                if (active) tab32[wi] = kMark;                            // min-lane tag through the word the slot lives in
+                if (active) atomicMin(&tab32[wi], lane);
+                if (active) first = tab32[wi];
+                const bool conf = active && first != lane;                // an earlier lane touches the same word
+                const uint32_t D = first_lane(__ballot(conf));            // 64 = none; the batch is cut after lane D
                 const uint32_t e_end = easy ? 64u : first_lane(__ballot(endk));
-                // candidate the sequential algorithm would see at lane k (k <= D)
-                uint32_t cand;
+                const uint32_t x_end = easy ? 64u : first_lane(__ballot(epk));
+                // lanes below D are alone in their word, so lane D's word holds exactly one earlier lane, fD: either the same
+                // slot (the collision the sequential algorithm would see) or the neighbouring slot (nothing to see)
+                uint32_t fD = 64u; bool true_dup = false;
+                if (D < 64u) {
+                    fD = __builtin_amdgcn_readlane(first, D) & 63u;
+                    true_dup = __builtin_amdgcn_readlane(h, D) == __builtin_amdgcn_readlane(h, fD);
+                }
+                // candidate the sequential algorithm would see at lane k (k <= D): the slot holds the low 16 bits of a
+                // position and the parity of its epoch; epochs older than the previous one were swept (sweep_to)
+                uint32_t cand; bool inwin;
                 {
-                    const uint64_t stored = old;
-                    cand = stored > base_off ? (uint32_t)(stored - base_off) : 0u;   // :70 saturating_sub
-                    if (D < 64u) {
-                        const uint32_t fD = __builtin_amdgcn_readlane(first, D);
-                        const uint32_t c_first = __builtin_amdgcn_readlane(ck, fD & 63u);
-                        if (lane == D) cand = c_first;
+                    const uint32_t s16 = (h & 1u) ? oldpair >> 16 : oldpair & 0xFFFFu;
+                    const uint32_t pb = (pw >> (h & 31u)) & 1u;
+                    const uint32_t ec = ck >> 16, xk = ck & 0xFFFFu;
+                    const bool same = pb == (ec & 1u);
+                    cand = ((same ? ec : ec - 1u) << 16) | s16;
+                    inwin = same ? s16 <= xk : (ec >= 1u && s16 > xk);   // <=> cand <= ck && ck - cand <= 0xFFFF (:200-201)
+                    if (true_dup && lane == D) {
+                        cand = __builtin_amdgcn_readlane(ck, fD);
+                        inwin = ck - cand <= 0xFFFFu;
                     }
                 }
                 // candidate side, one round trip: 16 bytes at the candidate for the >= 4 test and the
                 // forward extension, 8 bytes before both positions for the backtrack
-                const bool reach = active && lane <= D && ck != init && cand <= ck && ck - cand <= 0xFFFFu;   // :200-201
+                const bool reach = active && lane <= D && ck != init && inwin;
                 uint64_t B0 = 0, B1 = 0, PA = 0, PB = 0;
                 const bool btfast = cand >= 8u;        // (then ck >= 8 as well)
                 if (reach) {
@@ -190,22 +197,22 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                 int outcome;           // 0 = continue, 1 = match at W, 2 = end of input
                 if (W < e_end && W <= D) { commit_end = W + 1u; outcome = 1; }
                 else if (D < 64u) { commit_end = D + 1u; outcome = 0; }
-                else if (e_end < 64u) { commit_end = e_end; outcome = 2; }
+                else if (e_end < 64u && e_end <= x_end) { commit_end = e_end; outcome = 2; }
+                else if (x_end < 64u) { commit_end = x_end; outcome = 0; }
                 else { commit_end = bw; outcome = 0; }
-                // EncoderTable contract (:67/:92): position + offset must fit the slot type
-                if (!easy) {
-                    const bool bad = active && lane < commit_end && ((uint64_t)ck + base_off > TT::kLimit);
-                    if (__ballot(bad)) { status = LZF_CONTRACT; }
-                }
-                // ---- commit / roll back
-                if (active) {
-                    if (lane < commit_end) {
-                        // lane first[D] is overridden by D when D commits
-                        const uint32_t fD = D < 64u ? __builtin_amdgcn_readlane(first, D & 63u) : 64u;
-                        const bool overridden = (D < commit_end) && (lane == fD) && (lane != D);
-                        if (!overridden) tab[h] = ck + boff;
-                    } else if (first >= commit_end) {
-                        tab[h] = old;
+                // ---- commit: restore the tagged words, then write the positions the sequential code would have written
+                {
+                    const bool overridden = true_dup && D < commit_end && lane == fD;          // lane D writes that slot
+                    const bool commits = active && lane < commit_end && lane != D && !overridden;
+                    const uint32_t xk = ck & 0xFFFFu;
+                    const uint32_t newpair = (h & 1u) ? (oldpair & 0xFFFFu) | (xk << 16) : (oldpair & 0xFFFF0000u) | xk;
+                    if (active && !commits && lane != D) tab32[wi] = oldpair;                   // (lane D's word belongs to fD)
+                    if (commits) tab32[wi] = newpair;
+                    const bool dwrites = active && lane == D && D < commit_end;
+                    if (dwrites) tab16[h] = (uint16_t)xk;
+                    if (commits || dwrites) {
+                        const uint32_t bit = 1u << (h & 31u);
+                        if ((c >> 16) & 1u) atomicOr(&par[h >> 5], bit); else atomicAnd(&par[h >> 5], ~bit);
                     }
                 }
                 if (status != LZF_OK) break;
@@ -296,6 +303,7 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
                 }
             }
             cursor = m_pos + m;                                            // :215
+            if ((cursor >> 16) != swept) sweep_to(cursor >> 16);
             CPHASE(1);
             // The literal run is loaded first and the next run's first probes are requested right behind it, so
             // both travel in one round trip (loads return in order: storing the literals then waits for the
@@ -321,20 +329,21 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
             // table.replace(input, cursor - 2) — unconditional (:218, quirks B1/B3)
             {
                 const uint32_t q = cursor - 2u;
-                if ((uint64_t)q + base_off > TT::kLimit) { status = LZF_CONTRACT; break; }
                 uint64_t v8 = 0;
-                const uint32_t need = KIND == LZF_TABLE_U32 ? 8u : 4u;
-                if (KIND != LZF_TABLE_U32 || len - q >= 8u) {              // :43: fewer than 8 bytes left -> 0
-                    if (m - 2u + need <= 16u) {                            // still inside the winner's 16 bytes
+                if (len - q >= 8u) {                                       // :43: fewer than 8 bytes left -> 0
+                    if (m - 2u + 8u <= 16u) {                              // still inside the winner's 16 bytes
                         const uint32_t sh = (m - 2u) * 8u;
                         v8 = sh == 0u ? wA0 : sh < 64u ? ((wA0 >> sh) | (wA1 << (64u - sh))) : (wA1 >> (sh - 64u));
-                        if (KIND != LZF_TABLE_U32) v8 &= 0xFFFFFFFFull;
                     } else {
-                        v8 = KIND == LZF_TABLE_U32 ? ld8(in + q) : (uint64_t)ld4(in + q);
+                        v8 = ld8(in + q);
                     }
                 }
-                const uint32_t h = TT::hash(v8);
-                if (lane == 0) tab[h] = q + boff;
+                const uint32_t h = hash5(v8);
+                if (lane == 0) {
+                    tab16[h] = (uint16_t)q;
+                    const uint32_t bit = 1u << (h & 31u);
+                    if ((q >> 16) & 1u) atomicOr(&par[h >> 5], bit); else atomicAnd(&par[h >> 5], ~bit);
+                }
             }
             const uint32_t dup_offset = m_pos - m_cand;                    // :208
             const uint32_t extra = m - 4u + bt;                            // :206,:214
@@ -368,29 +377,11 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
             CPHASE(3);
         }
     }
-
-    // ---- table out (`&mut table`): mutations survive OUTPUT_FULL, like the reference's
-    if (job.table && !(job.flags & LZF_CJOB_TABLE_READONLY) && status != LZF_CONTRACT) {
-        if (KIND == LZF_TABLE_U32) {
-            LZF_GLOBAL lzf_u32_table* t = (LZF_GLOBAL lzf_u32_table*)job.table;
-            for (uint32_t i = lane; i < TT::kSlots; i += kWave) t->dict[i] = tab[i];
-        } else {
-            LZF_GLOBAL lzf_u16_table* t = (LZF_GLOBAL lzf_u16_table*)job.table;
-            for (uint32_t i = lane; i < TT::kSlots; i += kWave) t->dict[i] = (uint16_t)tab[i];
-        }
-    }
     if (lane == 0) {
         results[jid].out_len = s.pos;
         results[jid].status = status;
-#ifdef LZF_PHASE_TIMING
-        { uint32_t pk = 0; for (int i = 0; i < 4; ++i) { uint32_t u = (uint32_t)(g_tph[i] >> 23); if (u > 255u) u = 255u; pk |= u << (8 * i); } results[jid].reserved = pk; }
-#else
         results[jid].reserved = (uint32_t)((clock64() - t_start) >> 10);   // diagnostic: shader kilo-cycles spent on this job
-#endif
     }
 }
-
-template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U32>(const lzf_compress_job*, lzf_job_result*, uint32_t, uint32_t);
-template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U16>(const lzf_compress_job*, lzf_job_result*, uint32_t, uint32_t);
 
 }  // namespace lzf

@@ -1,0 +1,45 @@
+// lzf_compress_common.h — pieces shared by the compress kernels (skip schedule, bounded sink, LSIC coding).
+#pragma once
+#include "lzf_device.h"
+
+namespace lzf {
+
+// S(m) = sum of the first m advances of one literal run (mod.rs:174-175,225-231):
+// advance after probe j is 1 for j <= 65, then (62 + j) >> 6.
+__device__ __forceinline__ uint32_t sched_prefix(uint32_t m) {
+    if (m <= 66u) return m;
+    const uint32_t r = m - 66u;
+    const uint32_t full = r >> 6, rem = r & 63u;
+    return 66u + 64u * (full * (full - 1u) / 2u + 2u * full) + rem * (full + 2u);
+}
+
+constexpr uint32_t kMark = 0xFFFFFFFFu;
+constexpr uint32_t kMaxLen = 0x7FFFFF00u;
+constexpr uint32_t kFirstBatch = 16;     // lanes probing in the first batch of a literal run
+
+// Bounded sink with NoPartialWrites semantics (src/framed/compress.rs:294-314).
+struct Sink {
+    gu8* out;
+    uint32_t pos, cap;
+};
+
+// LSIC tail length in bytes (mod.rs:243-260): 0 if v < 15 else (v-15)/255 + 1.
+__device__ __forceinline__ uint32_t lsic_len(uint32_t v) { return v < 15u ? 0u : (v - 15u) / 255u + 1u; }
+
+__device__ __forceinline__ void lsic_store(gu8* dst, uint32_t v, uint32_t n, uint32_t lane) {
+    // n = lsic_len(v) > 0: n-1 bytes of 0xFF then (v-15) % 255
+    for (uint32_t i = lane; i < n; i += kWave) dst[i] = (i + 1u == n) ? (uint8_t)((v - 15u) % 255u) : (uint8_t)0xFF;
+}
+
+
+// Jobs the compact-table kernel (lz4_compress_compact.hip) takes instead of the general one: U32Table semantics with a
+// fresh table or a read-only template whose `offset` is 0 (every block the frame layer compresses in independent-
+// blocks mode, src/framed/compress.rs:220,265-270), positions below 2 GiB.
+__device__ __forceinline__ bool compress_job_is_compact(const lzf_compress_job& job) {
+    if (job.table_kind != LZF_TABLE_U32 || job.input_len >= kMaxLen || job.cursor > job.input_len) return false;
+    if (!job.table) return true;
+    if (!(job.flags & LZF_CJOB_TABLE_READONLY)) return false;
+    return ((const LZF_GLOBAL lzf_u32_table*)job.table)->offset == 0ull;
+}
+
+}  // namespace lzf
