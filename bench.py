@@ -235,7 +235,7 @@ def main():
                          "algorithmic_bytes_per_launch": d_bytes, "kernel_ms": round(d_kernel_ms, 4)},
             "compress": {"value": round(total_bytes * c_steps / tc_max / 2**30, 3), "unit": "GiB/s (uncompressed bytes compressed per second)",
                          "steps": c_steps, "ms_per_step": round(tc_max / c_steps * 1e3, 3),
-                         "roofline": {"bound": "hbm", "kernel": "lzf_compress_wave_kernel<U32>",
+                         "roofline": {"bound": "hbm", "kernel": "lzf_compress_compact_kernel",
                                       "achieved": round(c_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                       "frac": round(c_achieved / HBM_PEAK_GBS, 5), "traffic": c_traffic,
                                       "algorithmic_bytes_per_launch": c_bytes, "kernel_ms": round(c_kernel_ms, 3)}},

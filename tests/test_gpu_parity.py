@@ -168,6 +168,18 @@ def test_every_decompress_kernel_generation(variant):
     assert "variant ok" in r.stdout
 
 
+@pytest.mark.parametrize("kernel", ["compact", "general"])
+def test_every_compress_kernel(kernel):
+    """Fresh-table U32 jobs through the compact-table kernel (default) and through the general kernel: same bytes as
+    the oracle, over inputs that cross several 64 KiB epochs, skip epochs inside one match and widen the batches."""
+    import subprocess, sys
+    env = dict(os.environ, LZF_COMPRESS_KERNEL=kernel)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "compress_variant_check.py")], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "variant ok" in r.stdout
+
+
 def test_decompress_handcrafted_streams():
     """Blocks assembled sequence by sequence (tests/vectors.py synth_stream): shapes a greedy
     compressor never emits — > 1024 tokens per 8 KiB (token-list cut), multi-KiB literal runs and
