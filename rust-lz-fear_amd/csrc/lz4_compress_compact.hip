@@ -110,8 +110,85 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             bool more_m = false, more_bt = false;
             uint64_t wA0 = 0, wA1 = 0;        // the winner's 16 input bytes
 
+            // ================= search, fast form of a run's first batch (16 probes at cursor + lane, nowhere near the
+            // block's edges or an epoch boundary): most runs end here, so it is written out straight — the general batch
+            // below does the same with schedule arithmetic, end-of-input lanes and epoch cuts
+            bool found = false;
+            if (c > init && c >= 8u && (uint64_t)c + kFirstBatch + 40u <= len && (c >> 16) == swept &&
+                ((c + kFirstBatch - 1u) >> 16) == (c >> 16)) {
+                const bool inb = lane < kFirstBatch;
+                const uint32_t ck = c + lane;
+                uint64_t A0 = 0, A1 = 0;
+                if (pf_c == c) { A0 = pfA0; A1 = pfA1; }
+                else if (inb) { A0 = ld8(in + ck); A1 = ld8(in + ck + 8u); }
+                pf_c = 0xFFFFFFFFu;
+                const uint32_t h = hash5(A0);
+                const uint32_t wi = h >> 1;
+                uint32_t oldpair = 0, pw = 0, first = lane;
+                if (inb) { oldpair = tab32[wi]; pw = par[h >> 5]; tab32[wi] = kMark; atomicMin(&tab32[wi], lane); first = tab32[wi]; }
+                const uint32_t D = first_lane(__ballot(inb && first != lane));
+                uint32_t fD = 64u; bool true_dup = false;
+                if (D < 64u) {
+                    fD = __builtin_amdgcn_readlane(first, D) & 63u;
+                    true_dup = __builtin_amdgcn_readlane(h, D) == __builtin_amdgcn_readlane(h, fD);
+                }
+                const uint32_t s16 = (h & 1u) ? oldpair >> 16 : oldpair & 0xFFFFu;
+                const uint32_t ec = c >> 16, xk = ck & 0xFFFFu;
+                const bool same = ((pw >> (h & 31u)) & 1u) == (ec & 1u);
+                uint32_t cand = ((same ? ec : ec - 1u) << 16) | s16;
+                bool inwin = same ? s16 <= xk : (ec >= 1u && s16 > xk);
+                if (true_dup && lane == D) { cand = c + fD; inwin = true; }
+                const bool reach = inb && lane <= D && inwin;
+                uint64_t B0 = 0, B1 = 0, PA = 0, PB = 0;
+                const bool btfast = cand >= 8u;
+                if (reach) {
+                    B0 = ld8(in + cand); B1 = ld8(in + cand + 8u);
+                    if (btfast) { PA = ld8(in + ck - 8u); PB = ld8(in + cand - 8u); }
+                }
+                const bool valid = reach && (uint32_t)A0 == (uint32_t)B0;  // :204-206 (m >= 4)
+                const uint32_t W = first_lane(__ballot(valid));            // <= D whenever < 64
+                const uint32_t commit_end = W < 64u ? W + 1u : (D < 64u ? D + 1u : kFirstBatch);
+                {   // commit (see the general batch)
+                    const bool overridden = true_dup && D < commit_end && lane == fD;
+                    const bool commits = inb && lane < commit_end && lane != D && !overridden;
+                    const uint32_t newpair = (h & 1u) ? (oldpair & 0xFFFFu) | (xk << 16) : (oldpair & 0xFFFF0000u) | xk;
+                    if (inb && !commits && lane != D) tab32[wi] = oldpair;
+                    if (commits) tab32[wi] = newpair;
+                    const bool dwrites = inb && lane == D && D < commit_end;
+                    if (dwrites) tab16[h] = (uint16_t)xk;
+                    if (commits || dwrites) {
+                        const uint32_t bit = 1u << (h & 31u);
+                        if (ec & 1u) atomicOr(&par[h >> 5], bit); else atomicAnd(&par[h >> 5], ~bit);
+                    }
+                }
+                if (W < 64u) {
+                    uint32_t m_loc, bt_loc = 0;
+                    {
+                        const uint64_t x0 = A0 ^ B0, x1 = A1 ^ B1;
+                        m_loc = x0 ? (uint32_t)(__builtin_ctzll(x0) >> 3) : 8u + (x1 ? (uint32_t)(__builtin_ctzll(x1) >> 3) : 8u);
+                        if (btfast) { const uint64_t xp = PA ^ PB; bt_loc = xp ? (uint32_t)(__builtin_clzll(xp) >> 3) : 8u; }
+                    }
+                    m_pos = c + W;
+                    m_cand = __builtin_amdgcn_readlane(cand, W);
+                    const uint32_t alen_w = (len - 5u) - m_pos;            // :195
+                    const uint32_t mw = __builtin_amdgcn_readlane(m_loc, W);
+                    m = mw < alen_w ? mw : alen_w;
+                    more_m = mw >= 16u && alen_w > 16u;
+                    const uint32_t runlen = m_pos - ls;
+                    const uint32_t mbw = runlen < m_cand ? runlen : m_cand;  // :211-212 bounds
+                    const uint32_t btw = __builtin_amdgcn_readlane(bt_loc, W);
+                    const bool fastw = m_cand >= 8u;
+                    bt = fastw ? (btw < mbw ? btw : mbw) : 0u;
+                    more_bt = fastw ? (btw >= 8u && mbw > 8u) : (mbw > 0u);
+                    wA0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(A0 >> 32), W) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)A0, W);
+                    wA1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(A1 >> 32), W) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)A1, W);
+                    found = true;
+                } else {
+                    n = commit_end; c += commit_end;                       // the first 66 probes of a run advance by 1
+                }
+            }
             // ================= search: speculative batches of the :177-232 loop
-            for (;;) {
+            if (!found) for (;;) {
                 { const uint32_t eb = c >> 16; if (eb != swept) sweep_to(eb); }        // the batch base enters a new 64 KiB epoch
                 // Common case, decided once per batch with scalar compares: first batch of a run, not at
                 // the block's edges.  Then every lane is a plain probe (no schedule arithmetic, no end-of-

@@ -21,4 +21,8 @@ for it in range(reps):
     dt = time.time() - t
     print(f"jobs {m} raw {len(data)*copies} time {dt*1e3:.1f} ms  {len(data)*copies/dt/2**30:.2f} GiB/s", flush=True)
 res = device.results_to_host(d_res, m)
+if os.environ.get("LZF_PHASES"):
+    rv = res['reserved'][res['status'] == 0].astype(np.int64)
+    ph = [((rv >> (8 * k)) & 255).mean() * 8.39 for k in range(4)]
+    print("mean phase Mcycles per block: search %.0f extend %.0f prefetch/insert %.0f emit %.0f" % tuple(ph))
 print("status counts", np.unique(res['status'], return_counts=True), "sum out_len", int(res['out_len'][res['status']==0].sum()))
