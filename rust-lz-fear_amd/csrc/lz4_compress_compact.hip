@@ -43,6 +43,9 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
 
     cgu8* __restrict__ in = as_global(job.input);
     int status = LZF_OK;
+#ifdef LZF_PHASE_TIMING
+    long long g_tph[6] = {0, 0, 0, 0, 0, 0};
+#endif
     Sink s{as_global(job.out), 0u, job.out_cap > kMaxLen ? kMaxLen : (uint32_t)job.out_cap};
     {
         const uint32_t len = (uint32_t)job.input_len;
@@ -99,9 +102,29 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
         // as soon as the cursor is known (before the previous sequence is emitted) and consumed here.
         uint32_t pf_c = 0xFFFFFFFFu;
         uint64_t pfA0 = 0, pfA1 = 0;
+        uint32_t pend_q = 0xFFFFFFFFu;      // position of a `cursor - 2` insert whose bytes (pfQ, lane 16) are in flight
+        uint64_t pfQ = 0;
+        auto insert_at = [&](uint32_t q, uint64_t v8) {
+            const uint32_t h = hash5(v8);
+            if (lane == 0) {
+                tab16[h] = (uint16_t)q;
+                const uint32_t bit = 1u << (h & 31u);
+                if ((q >> 16) & 1u) atomicOr(&par[h >> 5], bit); else atomicAnd(&par[h >> 5], ~bit);
+            }
+        };
+#ifdef LZF_PHASE_TIMING
+        long long tq = clock64();
+#define CPHASE(i) do { const long long tn = clock64(); g_tph[i] += tn - tq; tq = tn; } while (0)
+#else
 #define CPHASE(i) do { } while (0)
+#endif
 
         while (cursor < len && status == LZF_OK) {                        // :171
+            if (pend_q != 0xFFFFFFFFu) {
+                const uint64_t v8 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(pfQ >> 32), 16) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)pfQ, 16);
+                insert_at(pend_q, v8);
+                pend_q = 0xFFFFFFFFu;
+            }
             const uint32_t ls = cursor;                                   // :172 literal_start
             uint32_t n = 0;          // probe index inside this literal run
             uint32_t c = cursor;     // position of probe n
@@ -147,6 +170,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 }
                 const bool valid = reach && (uint32_t)A0 == (uint32_t)B0;  // :204-206 (m >= 4)
                 const uint32_t W = first_lane(__ballot(valid));            // <= D whenever < 64
+                CPHASE(0);
                 const uint32_t commit_end = W < 64u ? W + 1u : (D < 64u ? D + 1u : kFirstBatch);
                 {   // commit (see the general batch)
                     const bool overridden = true_dup && D < commit_end && lane == fD;
@@ -315,7 +339,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 else c += sched_prefix(n) - (sn ? sn : sched_prefix(n - commit_end));
             }
             if (status != LZF_OK) break;
-            CPHASE(0);
+            CPHASE(1);
 
             if (finished) {
                 // ---- last literals, mod.rs:178-190
@@ -389,7 +413,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             const bool lit_fast = lit_len <= 1024u;
             uint32_t lit_b = 0, lit_t = 0; u32x4 lit_v = {0, 0, 0, 0};
             if (lit_fast) {
-                if (lit_len <= kWave) { if (lane < lit_len) lit_b = in[ls + lane]; }
+                if (lit_len < kWave) { if (lane >= 1u && lane <= lit_len) lit_b = in[ls + lane - 1u]; }   // lane j holds literal j-1
                 else {
                     const uint32_t bulk = lit_len & ~15u;
                     if (lane * 16u < bulk) lit_v = ld16(in + ls + lane * 16u);
@@ -403,24 +427,23 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 else if (lane < kFirstBatch && ckn <= len && len - ckn >= 12u) { pfA0 = ld8(in + ckn); pfA1 = ld8_part(ckn + 8u); }
                 pf_c = cursor;
             }
-            // table.replace(input, cursor - 2) — unconditional (:218, quirks B1/B3)
+            // table.replace(input, cursor - 2) — unconditional (:218, quirks B1/B3).  When the 8 bytes at cursor - 2 are
+            // not in the winner's registers they are requested with the probes (lane 16) and the insert is made at the top
+            // of the next iteration, before anything reads the table — no round trip of its own.
             {
                 const uint32_t q = cursor - 2u;
-                uint64_t v8 = 0;
+                bool now = true; uint64_t v8 = 0;
                 if (len - q >= 8u) {                                       // :43: fewer than 8 bytes left -> 0
                     if (m - 2u + 8u <= 16u) {                              // still inside the winner's 16 bytes
                         const uint32_t sh = (m - 2u) * 8u;
                         v8 = sh == 0u ? wA0 : sh < 64u ? ((wA0 >> sh) | (wA1 << (64u - sh))) : (wA1 >> (sh - 64u));
                     } else {
-                        v8 = ld8(in + q);
+                        now = false;
+                        if (lane == 16u) pfQ = ld8(in + q);
+                        pend_q = q;
                     }
                 }
-                const uint32_t h = hash5(v8);
-                if (lane == 0) {
-                    tab16[h] = (uint16_t)q;
-                    const uint32_t bit = 1u << (h & 31u);
-                    if ((q >> 16) & 1u) atomicOr(&par[h >> 5], bit); else atomicAnd(&par[h >> 5], ~bit);
-                }
+                if (now) insert_at(q, v8);
             }
             const uint32_t dup_offset = m_pos - m_cand;                    // :208
             const uint32_t extra = m - 4u + bt;                            // :206,:214
@@ -428,6 +451,19 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             // ================= write_group, mod.rs:150-163 (+ :235 literal slice)
             const uint32_t lit_end = cursor - extra - 4u;
             const uint32_t L = lit_end - ls;
+            if (L < 15u && extra < 15u) {
+                // the common sequence: token, up to 14 literals, offset — one byte per lane, one store
+                const uint32_t total = L + 3u;
+                if (s.cap - s.pos < total) { status = LZF_OUTPUT_FULL; break; }
+                uint32_t byte = lit_b;
+                if (lane == 0u) byte = (L << 4) | extra;
+                if (lane == L + 1u) byte = dup_offset;
+                if (lane == L + 2u) byte = dup_offset >> 8;
+                if (lane < total) s.out[s.pos + lane] = (uint8_t)byte;
+                s.pos += total;
+                CPHASE(3);
+                continue;
+            }
             const uint32_t nl = lsic_len(L), ne = lsic_len(extra);
             const uint32_t total = 1u + nl + L + 2u + ne;
             if (s.cap - s.pos < total) { status = LZF_OUTPUT_FULL; break; }
@@ -440,7 +476,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             if (nl) lsic_store(d + 1, L, nl, lane);
             if (lit_fast) {
                 gu8* ld = d + 1u + nl;
-                if (L <= kWave) { if (lane < L) ld[lane] = (uint8_t)lit_b; }
+                if (L < kWave) { if (lane >= 1u && lane <= L) ld[lane - 1u] = (uint8_t)lit_b; }
                 else {
                     const uint32_t bulk = L & ~15u;
                     if (lane * 16u < bulk) st16(ld + lane * 16u, lit_v);
@@ -457,7 +493,11 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
     if (lane == 0) {
         results[jid].out_len = s.pos;
         results[jid].status = status;
+#ifdef LZF_PHASE_TIMING
+        { uint32_t pk = 0; for (int i = 0; i < 4; ++i) { uint32_t u = (uint32_t)(g_tph[i] >> 23); if (u > 255u) u = 255u; pk |= u << (8 * i); } results[jid].reserved = pk; }
+#else
         results[jid].reserved = (uint32_t)((clock64() - t_start) >> 10);   // diagnostic: shader kilo-cycles spent on this job
+#endif
     }
 }
 

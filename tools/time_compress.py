@@ -25,4 +25,8 @@ if os.environ.get("LZF_PHASES"):
     rv = res['reserved'][res['status'] == 0].astype(np.int64)
     ph = [((rv >> (8 * k)) & 255).mean() * 8.39 for k in range(4)]
     print("mean phase Mcycles per block: search %.0f extend %.0f prefetch/insert %.0f emit %.0f" % tuple(ph))
+    allrv = res['reserved'].astype(np.int64).reshape(copies, n)
+    for b in (0, 4, 16, 19, 28, 31, 34, 38, 41, 47, 50):
+        v = allrv[:, b]; pb = [((v >> (8 * k)) & 255).mean() * 8.39 for k in range(4)]
+        print("  block %2d: %4.0f %4.0f %4.0f %4.0f  (status %d, out %d)" % (b, *pb, int(res['status'][b]), int(res['out_len'][b])))
 print("status counts", np.unique(res['status'], return_counts=True), "sum out_len", int(res['out_len'][res['status']==0].sum()))
