@@ -39,7 +39,7 @@ int ensure_device() {
 // Kernel variant used by lzf_decompress_batch.  Tuning / A-B knob only (every variant implements the same
 // contract): LZF_DECOMPRESS_KERNEL = wave (first generation, one sequence at a time) or one of the names in
 // LZF_DECOMPRESS_VARIANTS (kernels.h).  Unknown names select the default.
-enum { kVariantWave = 0, kVariantFirstBatched = 1, kVariantFirstWindowed = 100 };
+enum { kVariantWave = 0, kVariantFirstBatched = 1, kVariantFirstWindowed = 100, kVariantFirstPaired = 200 };
 #define LZF_DEFAULT_VARIANT "staged16"
 int decompress_variant() {
     static const int v = [] {
@@ -54,6 +54,10 @@ int decompress_variant() {
 #define LZF_NAMEW(NAME, RG, R_, W_) if (!strcmp(e, #NAME)) return id; if (!strcmp(LZF_DEFAULT_VARIANT, #NAME)) def = id; ++id;
         LZF_WINDOWED_VARIANTS(LZF_NAMEW)
 #undef LZF_NAMEW
+        id = kVariantFirstPaired;
+#define LZF_NAMEP(NAME, RG, S_, T) if (!strcmp(e, #NAME)) return id; if (!strcmp(LZF_DEFAULT_VARIANT, #NAME)) def = id; ++id;
+        LZF_PAIRED_VARIANTS(LZF_NAMEP)
+#undef LZF_NAMEP
         return def;
     }();
     return v;
@@ -113,6 +117,12 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
         if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<R, S_, T, ST>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs);
         LZF_DECOMPRESS_VARIANTS(LZF_LAUNCH)
 #undef LZF_LAUNCH
+    } else if (variant >= kVariantFirstPaired) {
+        int id = kVariantFirstPaired;
+#define LZF_LAUNCHP(NAME, RG, S_, T) \
+        if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_paired_kernel<RG, S_, T>), dim3(n_jobs), dim3(128), 0, st, d_jobs, d_results, n_jobs);
+        LZF_PAIRED_VARIANTS(LZF_LAUNCHP)
+#undef LZF_LAUNCHP
     } else {
         // windowed kernels keep each block's token list in a stream-ordered scratch area (freed when the kernels are done)
         uint32_t stride = 0;

@@ -12,6 +12,8 @@ __global__ void lzf_decompress_batched_kernel(const lzf_decompress_job* __restri
 // LZF_DECOMPRESS_KERNEL=<name> selects one (A/B knob; every variant implements the same contract).
 #define LZF_DECOMPRESS_VARIANTS(X) \
     X(staged16, 4096, 16, 256, true)    \
+    X(staged16r2, 2048, 16, 256, true)  \
+    X(staged12, 4096, 12, 192, true)  \
     X(staged24, 4096, 24, 384, true)    \
     X(staged32, 4096, 32, 512, true)    \
     X(staged32r2, 2048, 32, 512, true)  \
@@ -40,6 +42,16 @@ __global__ void lzf_decompress_windowed_kernel(const lzf_decompress_job* __restr
 #define LZF_EXTW(NAME, RG, R_, W_) extern template __global__ void lzf_decompress_windowed_kernel<RG, R_, W_>(const lzf_decompress_job*, lzf_job_result*, uint32_t, uint16_t*, uint32_t);
 LZF_WINDOWED_VARIANTS(LZF_EXTW)
 #undef LZF_EXTW
+// Producer / consumer pairs (lz4_decompress_paired.hip): X(name, ring bytes, region bytes, token-list entries).
+template <int RING, int S, int TOKCAP>
+__global__ void lzf_decompress_paired_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs);
+#define LZF_PAIRED_VARIANTS(X) \
+    X(paired16, 4096, 16, 256) \
+    X(paired24, 4096, 24, 384) \
+    X(paired32, 4096, 32, 512)
+#define LZF_EXTP(NAME, RG, S_, T) extern template __global__ void lzf_decompress_paired_kernel<RG, S_, T>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+LZF_PAIRED_VARIANTS(LZF_EXTP)
+#undef LZF_EXTP
 template <int KIND>
 __global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
                                          lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t skip_compact);
