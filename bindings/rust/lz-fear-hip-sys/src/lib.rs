@@ -69,4 +69,5 @@ extern "C" {
     pub fn lzf_table_offset(d_table: *mut c_void, table_kind: u32, add: u64, hip_stream: *mut c_void) -> c_int;
     pub fn lzf_xxh32_batch(d_ptrs: *const *const u8, d_lens: *const u64, d_out: *mut u32, n: u32,
                            hip_stream: *mut c_void) -> c_int;
+    pub fn lzf_copy_ranges(d_src: *const *const u8, d_dst: *const *mut u8, d_len: *const u64, n: u32, max_len: u64, hip_stream: *mut c_void) -> c_int;
 }

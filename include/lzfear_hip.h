@@ -141,6 +141,12 @@ int lzf_table_offset(void* d_table, uint32_t table_kind, uint64_t add, void* hip
 int lzf_xxh32_batch(const uint8_t* const* d_ptrs, const uint64_t* d_lens, uint32_t* d_out,
                     uint32_t n, void* hip_stream);
 
+/* Stored blocks: copies n device byte ranges (d_src[i] -> d_dst[i], d_len[i] bytes, each at most max_len) in one
+ * launch — the raw-block moves of src/framed/compress.rs:250-255 and src/framed/decompress.rs:250 without going
+ * through the host.  Ranges must not overlap each other. */
+int lzf_copy_ranges(const uint8_t* const* d_src, uint8_t* const* d_dst, const uint64_t* d_len, uint32_t n,
+                    uint64_t max_len, void* hip_stream);
+
 /* ---- host-buffer convenience (synchronous; stages through device scratch) ---------------
  * Same semantics as the batch calls but every pointer in the jobs is a HOST pointer and
  * `results` is a host array.  `table` pointers are host lzf_*_table structs, updated in

@@ -75,4 +75,21 @@ __global__ void lzf_table_offset_kernel(void* table, uint32_t kind, uint64_t add
     }
 }
 
+// Copies ranges [src[r], src[r] + len[r]) -> dst[r]: blockIdx.y = range, blockIdx.x = 64 KiB piece of it,
+// 256 threads x 16 bytes per step (unaligned 16-byte accesses are fine on gfx950).
+__global__ __launch_bounds__(256) void lzf_copy_ranges_kernel(const uint8_t* const* __restrict__ src, uint8_t* const* __restrict__ dst,
+                                                              const uint64_t* __restrict__ len, uint32_t n) {
+    const uint32_t r = blockIdx.y;
+    if (r >= n) return;
+    const uint64_t total = len[r];
+    const uint64_t a = (uint64_t)blockIdx.x * 65536ull;
+    if (a >= total) return;
+    const uint64_t b = a + 65536ull < total ? a + 65536ull : total;
+    cgu8* s = as_global(src[r]);
+    gu8* d = as_global(dst[r]);
+    uint64_t i = a + (uint64_t)threadIdx.x * 16ull;
+    for (; i + 16ull <= b; i += 256ull * 16ull) st16(d + i, ld16(s + i));
+    if (i < b) for (uint64_t t = i; t < b; ++t) d[t] = s[t];     // the piece's last, partial 16 bytes (one thread)
+}
+
 }  // namespace lzf

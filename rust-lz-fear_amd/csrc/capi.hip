@@ -175,6 +175,18 @@ int lzf_table_offset(void* d_table, uint32_t table_kind, uint64_t add, void* hip
     return LZF_OK;
 }
 
+int lzf_copy_ranges(const uint8_t* const* d_src, uint8_t* const* d_dst, const uint64_t* d_len, uint32_t n, uint64_t max_len, void* hip_stream) {
+    if (n == 0 || max_len == 0) return LZF_OK;
+    if (!d_src || !d_dst || !d_len) { g_last_error = "lzf_copy_ranges: NULL argument"; return LZF_E_INVALID; }
+    int rc = ensure_device();
+    if (rc < 0) return rc;
+    const uint64_t pieces = (max_len + 65535ull) / 65536ull;
+    if (pieces > 0x7FFFFFFFull || n > 65535u) { g_last_error = "lzf_copy_ranges: at most 65535 ranges per call"; return LZF_E_INVALID; }
+    hipLaunchKernelGGL(lzf::lzf_copy_ranges_kernel, dim3((uint32_t)pieces, n), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_src, d_dst, d_len, n);
+    HIP_TRY(hipGetLastError());
+    return LZF_OK;
+}
+
 int lzf_xxh32_batch(const uint8_t* const* d_ptrs, const uint64_t* d_lens, uint32_t* d_out, uint32_t n, void* hip_stream) {
     if (n == 0) return LZF_OK;
     if (!d_ptrs || !d_lens || !d_out) { g_last_error = "lzf_xxh32_batch: NULL argument"; return LZF_E_INVALID; }

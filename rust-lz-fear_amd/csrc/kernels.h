@@ -61,6 +61,8 @@ __global__ void lzf_compress_compact_kernel(const lzf_compress_job* __restrict__
                                             lzf_job_result* __restrict__ results, uint32_t n_jobs);
 __global__ void lzf_xxh32_kernel(const uint8_t* const* __restrict__ ptrs, const uint64_t* __restrict__ lens,
                                  uint32_t* __restrict__ out, uint32_t n);
+__global__ void lzf_copy_ranges_kernel(const uint8_t* const* __restrict__ src, uint8_t* const* __restrict__ dst,
+                                       const uint64_t* __restrict__ len, uint32_t n);
 __global__ void lzf_seed_table_kernel(lzf_u32_table* __restrict__ t, const uint8_t* __restrict__ dict, uint64_t dict_len);
 __global__ void lzf_table_offset_kernel(void* table, uint32_t kind, uint64_t add);
 }  // namespace lzf

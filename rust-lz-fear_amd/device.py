@@ -42,6 +42,11 @@ def xxh32_batch(d_ptrs, d_lens, d_out, n, stream=None):
     ffi.check(ffi.lib().lzf_xxh32_batch(d_ptrs.data_ptr(), d_lens.data_ptr(), d_out.data_ptr(), n, _stream_ptr(stream)))
 
 
+def copy_ranges(d_src_ptrs, d_dst_ptrs, d_lens, n, max_len, stream=None):
+    """Stored blocks moved on the device (lzf_copy_ranges); the three arrays are uint64 device tensors."""
+    ffi.check(ffi.lib().lzf_copy_ranges(d_src_ptrs.data_ptr(), d_dst_ptrs.data_ptr(), d_lens.data_ptr(), n, max_len, _stream_ptr(stream)))
+
+
 class BlockSet:
     """Equal-size independent blocks of one contiguous HBM buffer (the DP unit of
     src/framed/compress.rs:221-276 in independent-blocks mode): block i = data[i*bs : ...]."""

@@ -67,7 +67,7 @@ class FrameInfo(C.Structure):
 EXPORTS = [
     "lzf_abi_version", "lzf_last_error", "lzf_device_count", "lzf_compress_batch",
     "lzf_decompress_batch", "lzf_table_seed_from_dictionary", "lzf_table_offset",
-    "lzf_xxh32_batch", "lzf_compress_batch_host", "lzf_decompress_batch_host",
+    "lzf_xxh32_batch", "lzf_copy_ranges", "lzf_compress_batch_host", "lzf_decompress_batch_host",
 ]
 FRAME_EXPORTS = [
     "lzf_settings_default", "lzf_frame_compress_bound", "lzf_frame_compress", "lzf_frame_read_header",
@@ -107,6 +107,7 @@ def lib():
         L.lzf_table_seed_from_dictionary.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.lzf_table_offset.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
         L.lzf_xxh32_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.lzf_copy_ranges.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
         L.lzf_compress_batch_host.argtypes = [C.POINTER(CompressJob), C.POINTER(JobResult), C.c_uint32]
         L.lzf_decompress_batch_host.argtypes = [C.POINTER(DecompressJob), C.POINTER(JobResult), C.c_uint32]
         L.lzf_settings_default.argtypes = [C.POINTER(Settings)]

@@ -394,3 +394,25 @@ def test_full_size_silesia_blocks_bit_exact_and_roundtrip():
             n = int(blocks.lens[i])
             assert int(res2["out_len"][i]) == n
             assert np.array_equal(dec[i * bs:i * bs + n], data[i * bs:i * bs + n]), i
+
+
+def test_copy_ranges_stored_blocks():
+    """lzf_copy_ranges: arbitrary (unaligned, ragged, empty) device ranges copied in one launch."""
+    import torch
+    from rust_lz_fear_amd import device
+    rng = np.random.default_rng(8)
+    src = torch.from_numpy(rng.integers(0, 256, 3_000_000, dtype=np.uint8)).cuda()
+    dst = torch.zeros(3_200_000, dtype=torch.uint8, device="cuda")
+    lens = [0, 1, 15, 16, 17, 65535, 65536, 65537, 200_001, 1_000_003]
+    so = [5, 77, 1001, 4096, 12345, 70_000, 140_001, 300_003, 700_007, 1_500_001]
+    do, pos = [], 3
+    for n in lens:
+        do.append(pos); pos += n + 13
+    as_dev = lambda a: torch.from_numpy(np.asarray(a, dtype=np.uint64).view(np.int64)).cuda()
+    device.copy_ranges(as_dev([src.data_ptr() + x for x in so]), as_dev([dst.data_ptr() + x for x in do]), as_dev(lens),
+                       len(lens), max(lens))
+    torch.cuda.synchronize()
+    exp = np.zeros(3_200_000, dtype=np.uint8); s = src.cpu().numpy()
+    for n, a, b in zip(lens, so, do):
+        exp[b:b + n] = s[a:a + n]
+    assert np.array_equal(dst.cpu().numpy(), exp)
