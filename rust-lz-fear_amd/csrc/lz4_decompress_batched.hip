@@ -161,25 +161,26 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 for (uint32_t j = lane * 4u; j < kChunk; j += 4u * kWave) {
                     const uint32_t w0 = *reinterpret_cast<const uint32_t*>(&cbuf[j]);
                     const uint32_t w1 = *reinterpret_cast<const uint32_t*>(&cbuf[j + 4u]);
-                    uint32_t d[4], qa[4], m1[4]; bool bad[4], need[4];
+                    // value-coded instead of flag-coded: anything the table cannot express pushes the distance beyond 254
+                    uint32_t d[4], qa[4], m1[4], w[4];
 #pragma unroll
                     for (uint32_t t = 0; t < 4u; ++t) {
-                        const uint32_t w = t == 0 ? w0 : __builtin_amdgcn_alignbyte(w1, w0, t);   // bytes j+t, j+t+1, ...
-                        const uint32_t L0 = (w >> 4) & 15u, b1 = (w >> 8) & 255u;
-                        const bool ext = L0 == 15u;
-                        d[t] = 3u + L0 + (ext ? b1 + 1u : 0u);                  // to the first byte after the offset
-                        const uint32_t q = cstart + j + t + d[t];
-                        bad[t] = (ext && b1 == 255u) || q >= fe;
-                        need[t] = (w & 15u) == 15u;
-                        qa[t] = bad[t] ? 0u : q - cstart;
+                        w[t] = t == 0 ? w0 : __builtin_amdgcn_alignbyte(w1, w0, t);   // bytes j+t, j+t+1, ...
+                        const uint32_t L0 = (w[t] >> 4) & 15u, b1 = (w[t] >> 8) & 255u;
+                        uint32_t dd = 3u + L0 + (L0 == 15u ? b1 + 1u : 0u);     // to the first byte after the offset
+                        dd = (w[t] & 0xFFF0u) == 0xFFF0u ? 0x1000u : dd;         // nibble 15 and extension 0xFF
+                        const uint32_t q = cstart + j + t + dd;
+                        const bool over = q >= fe;
+                        d[t] = over ? 0x1000u : dd;
+                        qa[t] = over ? 0u : q - cstart;
                     }
                     lds_ld8x4(cbuf_a + qa[0], cbuf_a + qa[1], cbuf_a + qa[2], cbuf_a + qa[3], m1[0], m1[1], m1[2], m1[3]);
                     uint32_t o4 = 0;
 #pragma unroll
                     for (uint32_t t = 0; t < 4u; ++t) {
-                        const uint32_t dd = d[t] + (need[t] ? 1u : 0u);
-                        const bool b = bad[t] || (need[t] && m1[t] == 255u) || dd > 254u;
-                        o4 |= (b ? 255u : dd) << (8u * t);
+                        const uint32_t inc = (w[t] & 15u) == 15u ? (m1[t] == 255u ? 0x1000u : 1u) : 0u;
+                        const uint32_t dd = d[t] + inc;
+                        o4 |= (dd < 255u ? dd : 255u) << (8u * t);
                     }
                     *reinterpret_cast<uint32_t*>(&nxt[j]) = o4;
                 }
