@@ -5,17 +5,20 @@
 // data-dependent hop per sequence), so this kernel splits decoding into two stages per chunk
 // of compressed input:
 //
-//   PARSE (lane-parallel, speculative).  A chunk is 64 regions of S bytes, one per lane.  Every
-//   lane walks the token chain of its region at once, starting from a guess (the region start).
-//   A walk from a wrong position re-synchronises with the true chain after a few hops, and the
-//   exit of a region (first token at or beyond its end) is the true start of the next one, so
-//   the wave iterates  start[i] <- max(exit[0..i-1])  until nothing changes; lane 0 starts from a
-//   known-true token, hence the fixed point is the true chain (lane i is exact after i+1
-//   passes at worst; typical data needs 3-4).  A final pass records the token positions,
-//   compacted in stream order, into an LDS list.
-//
-//   The chunk's compressed bytes are staged in LDS first (one coalesced 16 B/lane pass), so every
-//   hop of the walks, every token re-read and every literal copy is an LDS access.
+//   PARSE (lane-parallel, speculative).  A chunk is 64 regions of S bytes, one per lane.  The exit of
+//   a region (first token at or beyond its end) is the true start of the next one, so the wave
+//   iterates  start[i] <- max(exit[0..i-1])  until nothing changes; lane 0 starts from a known-true
+//   token, hence the fixed point is the true chain (lane i is exact after i+1 passes at worst).
+//   How a lane gets its region's exit depends on the variant:
+//     STAGE = true  (default, S = 16): the chunk is staged in LDS with one coalesced 16 B/lane pass;
+//       nxt[] = distance to the next token for EVERY byte position (all lanes busy, no dependent chain),
+//       ex[] = per region, exit for every entry offset (one backward sweep over nxt[]); a pass of the
+//       fixed point is then one table lookup per lane.  Counting and recording the tokens is a
+//       hand-scheduled hop loop over nxt[] (lzf_parse_helpers.h).  Every later access to compressed
+//       bytes (token re-read, offsets, literals) is an LDS access too.
+//     STAGE = false (direct4/4w, S = 128/256): a lane walks its region hop by hop reading tokens from
+//       HBM/L2 (hand-scheduled loop as well); first guesses come from a warm-up walk.
+//   A final pass records the token positions, compacted in stream order, into an LDS list.
 //
 //   COPY (lane-parallel, batched).  64 consecutive sequences go to the 64 lanes.  The most
 //   recent RING bytes of output live in an LDS ring (ring index == output address mod RING, so
@@ -23,12 +26,12 @@
 //   and its match with "two-ended" pieces (first and last 8/4/2 bytes, any alignment: gfx950
 //   executes misaligned DS accesses), so a run of up to 32 bytes costs at most 4 LDS reads and
 //   4 LDS writes.  "far" matches (older than the ring's intact history) are read back from HBM;
-//   "near" matches copy ring -> ring — all lanes at once when their source lies below the first
-//   unresolved match, the remainder strictly in stream order.  Overlapping matches use dst[t] = src[t mod offset], whose reads
-//   all precede the match.  LDS executes one wave's accesses in order, so no barrier or wait
+//   "near" matches copy ring -> ring in rounds: every match whose source ends below the start of the
+//   first unresolved match moves at once.  Overlapping matches use dst[t] = src[t mod offset], whose
+//   reads all precede the match.  LDS executes one wave's accesses in order, so no barrier or wait
 //   separates dependent copies.  The finished batch is flushed ring -> HBM with aligned
 //   16-byte stores: every output byte is written to HBM exactly once, coalesced.
-//   A sequence too large for a batch (> RING/4 output bytes) takes a solo path (cooperative
+//   A sequence too large for a batch (> RING/3 output bytes) takes a solo path (cooperative
 //   HBM -> HBM copies, then the ring is re-filled from HBM).
 //
 // Error precedence is the reference's: within a sequence literal EOF / LSIC EOF
@@ -255,9 +258,9 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                     // bytes, the end of the input); such lanes are served below by the general routine.
                     if (!STAGE) {
                         uint32_t lim = go ? stop : 0u;
-                        if (RECORD.value) hop_loop_record<false>(p, lim, n, k, cutpos_w, in, fast_end, pclamp, cstart, lds_addr(toks), (uint32_t)TOKCAP,
+                        if (RECORD.value) hop_loop_record(p, lim, n, k, cutpos_w, in, fast_end, pclamp, cstart, lds_addr(toks), (uint32_t)TOKCAP,
                                                                  lds_addr(toks) + 2u * ((uint32_t)TOKCAP + lane));
-                        else hop_loop<false>(p, lim, n, in, fast_end, pclamp);
+                        else hop_loop(p, lim, n, in, fast_end, pclamp);
                     } else {
                         // nxt[] coordinates: position - cstart + address of nxt
                         const uint32_t base = nxt_a - cstart;

@@ -222,9 +222,9 @@ __global__ __launch_bounds__(128) void lzf_decompress_paired_kernel(
                         // bytes, the end of the input); such lanes are served below by the general routine.
                         if (!STAGE) {
                             uint32_t lim = go ? stop : 0u;
-                            if (RECORD.value) hop_loop_record<false>(p, lim, n, k, cutpos_w, in, fast_end, pclamp, cstart, lds_addr(toks), (uint32_t)TOKCAP,
+                            if (RECORD.value) hop_loop_record(p, lim, n, k, cutpos_w, in, fast_end, pclamp, cstart, lds_addr(toks), (uint32_t)TOKCAP,
                                                                      lds_addr(toks) + 4u * ((uint32_t)TOKCAP + lane));
-                            else hop_loop<false>(p, lim, n, in, fast_end, pclamp);
+                            else hop_loop(p, lim, n, in, fast_end, pclamp);
                         } else {
                             // nxt[] coordinates: position - cstart + address of nxt
                             const uint32_t base = nxt_a - cstart;

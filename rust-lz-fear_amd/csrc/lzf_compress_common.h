@@ -15,7 +15,10 @@ __device__ __forceinline__ uint32_t sched_prefix(uint32_t m) {
 
 constexpr uint32_t kMark = 0xFFFFFFFFu;
 constexpr uint32_t kMaxLen = 0x7FFFFF00u;
-constexpr uint32_t kFirstBatch = 16;     // lanes probing in the first batch of a literal run
+#ifndef LZF_FIRST_BATCH
+#define LZF_FIRST_BATCH 16
+#endif
+constexpr uint32_t kFirstBatch = LZF_FIRST_BATCH;     // lanes probing in the first batch of a literal run
 
 // Bounded sink with NoPartialWrites semantics (src/framed/compress.rs:294-314).
 struct Sink {

@@ -55,7 +55,6 @@ namespace {
     "s_branch Lhop_loop%=\n" \
     "Lhop_done%=:"
 #define LZF_HOP_GLB LZF_HOP_HEAD("global_load_dword %[w], %[pa], %[in]\n\t", "global_load_ubyte %[m], %[m], %[in]\n\t", "s_waitcnt vmcnt(0)\n\t")
-#define LZF_HOP_LDS LZF_HOP_HEAD("ds_read_b32 %[w], %[pa]\n\t", "ds_read_u8 %[m], %[m]\n\t", "s_waitcnt lgkmcnt(0)\n\t")
 #define LZF_HOP_RECORD \
     "v_cndmask_b32 %[kk], -1, %[k], vcc\n\t" \
     "v_addc_co_u32_e64 %[k], %[sx], 0, %[k], vcc\n\t" \
@@ -66,36 +65,19 @@ namespace {
     "ds_write_b16 %[m], %[t]\n\t" \
     "v_cmp_eq_u32_e64 %[sx], %[cap], %[kk]\n\t" \
     "v_cndmask_b32_e64 %[cut], %[cut], %[pa], %[sx]\n\t"
-// STAGED selects the LDS form: p, lim, fast_end, pclamp and `cut` are then LDS byte addresses of the staged
-// chunk (position - cstart + address of cbuf) and `cstart` is the address of cbuf.
-template <bool STAGED>
 __device__ __forceinline__ void hop_loop(uint32_t& p, uint32_t& lim, uint32_t& n, cgu8* in, uint32_t fast_end, uint32_t pclamp) {
     uint32_t pa, w, q, t, m; uint64_t sx;
-    if (STAGED)
-        asm volatile(LZF_HOP_LDS LZF_HOP_TAIL
-                     : [p] "+v"(p), [lim] "+v"(lim), [n] "+v"(n), [pa] "=&v"(pa), [w] "=&v"(w), [q] "=&v"(q), [t] "=&v"(t), [m] "=&v"(m), [sx] "=&s"(sx)
-                     : [fend] "s"(fast_end), [pclamp] "s"(pclamp)
-                     : "vcc", "memory");
-    else
-        asm volatile(LZF_HOP_GLB LZF_HOP_TAIL
-                     : [p] "+v"(p), [lim] "+v"(lim), [n] "+v"(n), [pa] "=&v"(pa), [w] "=&v"(w), [q] "=&v"(q), [t] "=&v"(t), [m] "=&v"(m), [sx] "=&s"(sx)
-                     : [in] "s"(in), [fend] "s"(fast_end), [pclamp] "s"(pclamp)
-                     : "vcc", "memory");
+    asm volatile(LZF_HOP_GLB LZF_HOP_TAIL
+                 : [p] "+v"(p), [lim] "+v"(lim), [n] "+v"(n), [pa] "=&v"(pa), [w] "=&v"(w), [q] "=&v"(q), [t] "=&v"(t), [m] "=&v"(m), [sx] "=&s"(sx)
+                 : [in] "s"(in), [fend] "s"(fast_end), [pclamp] "s"(pclamp)
+                 : "vcc", "memory");
 }
 // Same, recording the token positions (relative to cstart) at toks[k++]; positions past the list's
 // capacity go to the lane's dump slot and the position of token #cap is kept in `cut`.
-template <bool STAGED>
 __device__ __forceinline__ void hop_loop_record(uint32_t& p, uint32_t& lim, uint32_t& n, uint32_t& k, uint32_t& cut, cgu8* in,
                                                 uint32_t fast_end, uint32_t pclamp, uint32_t cstart, uint32_t toks_a, uint32_t cap, uint32_t dump_a) {
     uint32_t pa, w, q, t, m, kk; uint64_t sx;
-    if (STAGED)
-        asm volatile(LZF_HOP_LDS LZF_HOP_RECORD LZF_HOP_TAIL
-                     : [p] "+v"(p), [lim] "+v"(lim), [n] "+v"(n), [k] "+v"(k), [cut] "+v"(cut), [pa] "=&v"(pa), [w] "=&v"(w), [q] "=&v"(q),
-                       [t] "=&v"(t), [m] "=&v"(m), [kk] "=&v"(kk), [sx] "=&s"(sx)
-                     : [fend] "s"(fast_end), [pclamp] "s"(pclamp), [cstart] "s"(cstart), [toksa] "s"(toks_a), [cap] "s"(cap), [dump] "v"(dump_a)
-                     : "vcc", "memory");
-    else
-        asm volatile(LZF_HOP_GLB LZF_HOP_RECORD LZF_HOP_TAIL
+    asm volatile(LZF_HOP_GLB LZF_HOP_RECORD LZF_HOP_TAIL
                      : [p] "+v"(p), [lim] "+v"(lim), [n] "+v"(n), [k] "+v"(k), [cut] "+v"(cut), [pa] "=&v"(pa), [w] "=&v"(w), [q] "=&v"(q),
                        [t] "=&v"(t), [m] "=&v"(m), [kk] "=&v"(kk), [sx] "=&s"(sx)
                      : [in] "s"(in), [fend] "s"(fast_end), [pclamp] "s"(pclamp), [cstart] "s"(cstart), [toksa] "s"(toks_a), [cap] "s"(cap), [dump] "v"(dump_a)
