@@ -327,15 +327,13 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 start = lane == 0 ? cstart : rbeg;
                 bool redo = true;
                 for (uint32_t pass = 0; pass < 70u; ++pass) {
-                    bool hard = false;
-                    if (redo) {
-                        if (start >= rend) x = start;                 // the chain jumps over this region
-                        else {
-                            const uint32_t e = lds_ld8(exl + (start - rbeg));
-                            x = rend + e;
-                            hard = e >= 254u;
-                        }
-                    }
+                    // branch-free: every lane looks its exit up every pass (same result for an unchanged start); only the rare
+                    // entries the table cannot express (254 / 255) are walked, and only when the start has changed
+                    const bool inreg = start < rend;                  // else the chain jumps over this region
+                    const uint32_t e = lds_ld8(exl + (inreg ? start - rbeg : 0u));
+                    const bool hc = inreg && e >= 254u;
+                    const bool hard = hc && redo;
+                    if (!hc) x = inreg ? rend + e : start;
                     if (__any(hard)) {                                // rare: walk it (0xFF runs, long literals, end of input)
                         uint32_t n1 = 0; bool e1 = false;
                         const uint32_t x1 = walk(start, rend, n1, kdummy, e1, hard, No{});
