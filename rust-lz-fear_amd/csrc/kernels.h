@@ -12,8 +12,6 @@ __global__ void lzf_decompress_batched_kernel(const lzf_decompress_job* __restri
 // LZF_DECOMPRESS_KERNEL=<name> selects one (A/B knob; every variant implements the same contract).
 #define LZF_DECOMPRESS_VARIANTS(X) \
     X(staged16, 4096, 16, 256, true)    \
-    X(staged16r2, 2048, 16, 256, true)  \
-    X(staged12, 4096, 12, 192, true)  \
     X(staged24, 4096, 24, 384, true)    \
     X(staged32, 4096, 32, 512, true)    \
     X(staged32r2, 2048, 32, 512, true)  \
