@@ -181,8 +181,12 @@ int lzf_copy_ranges(const uint8_t* const* d_src, uint8_t* const* d_dst, const ui
     int rc = ensure_device();
     if (rc < 0) return rc;
     const uint64_t pieces = (max_len + 65535ull) / 65536ull;
-    if (pieces > 0x7FFFFFFFull || n > 65535u) { g_last_error = "lzf_copy_ranges: at most 65535 ranges per call"; return LZF_E_INVALID; }
-    hipLaunchKernelGGL(lzf::lzf_copy_ranges_kernel, dim3((uint32_t)pieces, n), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_src, d_dst, d_len, n);
+    if (pieces > 0x7FFFFFFFull) { g_last_error = "lzf_copy_ranges: max_len too large"; return LZF_E_INVALID; }
+    for (uint32_t base = 0; base < n; base += 65535u) {              // grid.y is limited to 65535
+        const uint32_t cnt = n - base < 65535u ? n - base : 65535u;
+        hipLaunchKernelGGL(lzf::lzf_copy_ranges_kernel, dim3((uint32_t)pieces, cnt), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                           d_src + base, d_dst + base, d_len + base, cnt);
+    }
     HIP_TRY(hipGetLastError());
     return LZF_OK;
 }
