@@ -139,6 +139,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             bool found = false;
             if (c > init && c >= 8u && (uint64_t)c + kFirstBatch + 40u <= len && (c >> 16) == swept &&
                 ((c + kFirstBatch - 1u) >> 16) == (c >> 16)) {
+                bool fast_done = true;
                 const bool inb = lane < kFirstBatch;
                 const uint32_t ck = c + lane;
                 uint64_t A0 = 0, A1 = 0;
@@ -149,41 +150,37 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 const uint32_t wi = h >> 1;
                 uint32_t oldpair = 0, pw = 0, first = lane;
                 if (inb) { oldpair = tab32[wi]; pw = par[h >> 5]; tab32[wi] = kMark; atomicMin(&tab32[wi], lane); first = tab32[wi]; }
-                const uint32_t D = first_lane(__ballot(inb && first != lane));
-                uint32_t fD = 64u; bool true_dup = false;
-                if (D < 64u) {
-                    fD = __builtin_amdgcn_readlane(first, D) & 63u;
-                    true_dup = __builtin_amdgcn_readlane(h, D) == __builtin_amdgcn_readlane(h, fD);
+                if (__ballot(inb && first != lane)) {
+                    // two probes share a table word: put the words back and let the general batch sort it out
+                    if (inb) tab32[wi] = oldpair;
+                    pfA0 = A0; pfA1 = A1; pf_c = c;          // the general batch starts from the same 16 probes
+                    fast_done = false;
                 }
+                uint32_t W = 64u, cand = 0; uint64_t B0 = 0, B1 = 0, PA = 0, PB = 0; bool btfast = false;
+                if (fast_done) {
                 const uint32_t s16 = (h & 1u) ? oldpair >> 16 : oldpair & 0xFFFFu;
                 const uint32_t ec = c >> 16, xk = ck & 0xFFFFu;
                 const bool same = ((pw >> (h & 31u)) & 1u) == (ec & 1u);
-                uint32_t cand = ((same ? ec : ec - 1u) << 16) | s16;
-                bool inwin = same ? s16 <= xk : (ec >= 1u && s16 > xk);
-                if (true_dup && lane == D) { cand = c + fD; inwin = true; }
-                const bool reach = inb && lane <= D && inwin;
-                uint64_t B0 = 0, B1 = 0, PA = 0, PB = 0;
-                const bool btfast = cand >= 8u;
+                cand = ((same ? ec : ec - 1u) << 16) | s16;
+                const bool reach = inb && (same ? s16 <= xk : (ec >= 1u && s16 > xk));   // <=> cand <= ck && ck - cand <= 0xFFFF
+                btfast = cand >= 8u;
                 if (reach) {
                     B0 = ld8(in + cand); B1 = ld8(in + cand + 8u);
                     if (btfast) { PA = ld8(in + ck - 8u); PB = ld8(in + cand - 8u); }
                 }
                 const bool valid = reach && (uint32_t)A0 == (uint32_t)B0;  // :204-206 (m >= 4)
-                const uint32_t W = first_lane(__ballot(valid));            // <= D whenever < 64
+                W = first_lane(__ballot(valid));
                 CPHASE(0);
-                const uint32_t commit_end = W < 64u ? W + 1u : (D < 64u ? D + 1u : kFirstBatch);
-                {   // commit (see the general batch)
-                    const bool overridden = true_dup && D < commit_end && lane == fD;
-                    const bool commits = inb && lane < commit_end && lane != D && !overridden;
+                {   // commit: lanes up to the winner (all 16 without one) write their position, the others restore their word
+                    const uint32_t last = W < 64u ? W : kFirstBatch - 1u;
                     const uint32_t newpair = (h & 1u) ? (oldpair & 0xFFFFu) | (xk << 16) : (oldpair & 0xFFFF0000u) | xk;
-                    if (inb && !commits && lane != D) tab32[wi] = oldpair;
-                    if (commits) tab32[wi] = newpair;
-                    const bool dwrites = inb && lane == D && D < commit_end;
-                    if (dwrites) tab16[h] = (uint16_t)xk;
-                    if (commits || dwrites) {
+                    if (inb) tab32[wi] = lane <= last ? newpair : oldpair;
+                    if (inb && lane <= last) {
                         const uint32_t bit = 1u << (h & 31u);
                         if (ec & 1u) atomicOr(&par[h >> 5], bit); else atomicAnd(&par[h >> 5], ~bit);
                     }
+                    if (W >= 64u) { n = kFirstBatch; c += kFirstBatch; }   // the first 66 probes of a run advance by 1
+                }
                 }
                 if (W < 64u) {
                     uint32_t m_loc, bt_loc = 0;
@@ -207,8 +204,6 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     wA0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(A0 >> 32), W) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)A0, W);
                     wA1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(A1 >> 32), W) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)A1, W);
                     found = true;
-                } else {
-                    n = commit_end; c += commit_end;                       // the first 66 probes of a run advance by 1
                 }
             }
             // ================= search: speculative batches of the :177-232 loop
