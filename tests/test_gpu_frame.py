@@ -267,3 +267,43 @@ def test_streaming_reader_matches_decompress_frame():
     f = o.frame_compress(data, o.make_settings(block_size=64 << 10, independent_blocks=False, dictionary=d, dictionary_id=9))[1]
     r = framed.LZ4FrameReader(io.BytesIO(f), dictionary=d)
     assert r.dictionary_id() == 9 and r.read() == data
+
+
+def test_config4_sharded_frame_over_rccl():
+    """BASELINE config 4 on one GPU: blocks of a log-text stream compressed on the device, the size table and
+    the payloads all-gathered over torch.distributed's nccl backend (= RCCL; world_size 1 here, the 2-rank
+    exchange is covered on gloo by tests/test_dist_gloo.py), the frame assembled — byte-identical to the oracle's
+    frame, and it decodes back."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from rust_lz_fear_amd import device, ffi, dist as lzdist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        BS = 4 << 20
+        data = synth.log_text(0, 5 * BS + 1_234_567)
+        d_in = torch.from_numpy(data).cuda()
+        blocks = device.BlockSet(d_in, BS); n = blocks.n
+        d_out = torch.empty(n * BS, dtype=torch.uint8, device="cuda")
+        d_res = torch.zeros(n * 16, dtype=torch.uint8, device="cuda")
+        device.compress_batch(device.to_device(blocks.compress_jobs(d_out, BS), "cuda"), d_res, n)
+        torch.cuda.synchronize()
+        res = device.results_to_host(d_res, n)
+        lo, hi = lzdist.shard_range(n, 0, 1)
+        payloads, clens = [], []
+        for b in range(lo, hi):
+            if res["status"][b] == 0:
+                payloads.append(d_out[b * BS: b * BS + int(res["out_len"][b])]); clens.append(int(res["out_len"][b]))
+            else:
+                payloads.append(d_in[b * BS: min((b + 1) * BS, len(data))]); clens.append(lzdist.STORED)
+        allp, allc = lzdist.allgather_blocks(payloads, clens, n, device="cuda")
+        raw_len = [min(BS, len(data) - b * BS) for b in range(n)]
+        raw = data.tobytes()
+        st = framed.CompressionSettings().block_size(BS)._struct(None)
+        frame = lzdist.assemble_frame(st, allp, allc, raw_len, ffi.lib().lzf_xxh32(raw, len(raw), 0))
+        assert frame == o.frame_compress(raw, o.make_settings(block_size=BS))[1]
+        assert framed.decompress_frame(frame) == raw
+    finally:
+        dist.destroy_process_group()
