@@ -242,7 +242,7 @@ def main():
                                    (copies, float(lens.sum()) / float(clen.sum() + lens[stored_idx].sum())),
                        "blocks_per_gpu": int(nblk), "stored_blocks_per_gpu": int(len(stored_idx)),
                        "block_size": BS, "parallelism": f"block-sharded x{world}, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "lzf_decompress_batched_kernel<4096,16,256,staged>",
+            "roofline": {"bound": "hbm", "kernel": "lzf_decompress_paired_kernel<4096,24,384>",
                          "achieved": round(d_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(d_achieved / HBM_PEAK_GBS, 5), "traffic": d_traffic,
                          "algorithmic_bytes_per_launch": d_bytes, "kernel_ms": round(d_kernel_ms, 4)},

@@ -39,28 +39,37 @@ int ensure_device() {
 // Kernel variant used by lzf_decompress_batch.  Tuning / A-B knob only (every variant implements the same
 // contract): LZF_DECOMPRESS_KERNEL = wave (first generation, one sequence at a time) or one of the names in
 // LZF_DECOMPRESS_VARIANTS (kernels.h).  Unknown names select the default.
-enum { kVariantWave = 0, kVariantFirstBatched = 1, kVariantFirstWindowed = 100, kVariantFirstPaired = 200 };
-#define LZF_DEFAULT_VARIANT "staged16"
-int decompress_variant() {
-    static const int v = [] {
-        const char* e = getenv("LZF_DECOMPRESS_KERNEL");
-        if (!e || !*e) e = LZF_DEFAULT_VARIANT;
-        if (!strcmp(e, "wave")) return (int)kVariantWave;
-        int id = kVariantFirstBatched, def = -1;
-#define LZF_NAME(NAME, R, S_, T, ST) if (!strcmp(e, #NAME)) return id; if (!strcmp(LZF_DEFAULT_VARIANT, #NAME)) def = id; ++id;
-        LZF_DECOMPRESS_VARIANTS(LZF_NAME)
+enum { kVariantAuto = -1, kVariantWave = 0, kVariantFirstBatched = 1, kVariantFirstWindowed = 100, kVariantFirstPaired = 200 };
+// Variant by name; "auto" (the default) = the producer/consumer pair kernel, with 48-byte regions while every block's
+// workgroup is resident at once (lowest latency per block: the copy stage is the critical path, the parse rides along)
+// and 24-byte regions beyond that (smaller LDS footprint, more blocks in flight).
+static int variant_by_name(const char* e) {
+    if (!strcmp(e, "auto")) return kVariantAuto;
+    if (!strcmp(e, "wave")) return kVariantWave;
+    int id = kVariantFirstBatched;
+#define LZF_NAME(NAME, R, S_, T, ST) if (!strcmp(e, #NAME)) return id; ++id;
+    LZF_DECOMPRESS_VARIANTS(LZF_NAME)
 #undef LZF_NAME
-        id = kVariantFirstWindowed;
-#define LZF_NAMEW(NAME, RG, R_, W_) if (!strcmp(e, #NAME)) return id; if (!strcmp(LZF_DEFAULT_VARIANT, #NAME)) def = id; ++id;
-        LZF_WINDOWED_VARIANTS(LZF_NAMEW)
+    id = kVariantFirstWindowed;
+#define LZF_NAMEW(NAME, RG, R_, W_) if (!strcmp(e, #NAME)) return id; ++id;
+    LZF_WINDOWED_VARIANTS(LZF_NAMEW)
 #undef LZF_NAMEW
-        id = kVariantFirstPaired;
-#define LZF_NAMEP(NAME, RG, S_, T) if (!strcmp(e, #NAME)) return id; if (!strcmp(LZF_DEFAULT_VARIANT, #NAME)) def = id; ++id;
-        LZF_PAIRED_VARIANTS(LZF_NAMEP)
+    id = kVariantFirstPaired;
+#define LZF_NAMEP(NAME, RG, S_, T) if (!strcmp(e, #NAME)) return id; ++id;
+    LZF_PAIRED_VARIANTS(LZF_NAMEP)
 #undef LZF_NAMEP
-        return def;
+    return kVariantAuto;                       // unknown names select the default
+}
+int decompress_variant(uint32_t n_jobs) {
+    static const int v = [] { const char* e = getenv("LZF_DECOMPRESS_KERNEL"); return (e && *e) ? variant_by_name(e) : (int)kVariantAuto; }();
+    if (v != kVariantAuto) return v;
+    static const int small = variant_by_name("paired48"), large = variant_by_name("paired24");
+    static const uint32_t resident48 = [] {     // workgroups of the 48-byte form one device holds: 8 per CU (20 KB of LDS each)
+        hipDeviceProp_t p; int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 2048u;
+        return 8u * (uint32_t)p.multiProcessorCount;
     }();
-    return v;
+    return n_jobs <= resident48 ? small : large;
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -108,7 +117,7 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
     int rc = ensure_device();
     if (rc < 0) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
-    const int variant = decompress_variant();
+    const int variant = decompress_variant(n_jobs);
     if (variant == kVariantWave) {
         hipLaunchKernelGGL(lzf::lzf_decompress_wave_kernel, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs);
     } else if (variant < kVariantFirstWindowed) {

@@ -46,7 +46,8 @@ __global__ void lzf_decompress_paired_kernel(const lzf_decompress_job* __restric
 #define LZF_PAIRED_VARIANTS(X) \
     X(paired16, 4096, 16, 256) \
     X(paired24, 4096, 24, 384) \
-    X(paired32, 4096, 32, 512)
+    X(paired32, 4096, 32, 512) \
+    X(paired48, 4096, 48, 640)
 #define LZF_EXTP(NAME, RG, S_, T) extern template __global__ void lzf_decompress_paired_kernel<RG, S_, T>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
 LZF_PAIRED_VARIANTS(LZF_EXTP)
 #undef LZF_EXTP
