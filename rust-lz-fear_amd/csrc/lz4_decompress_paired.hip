@@ -37,7 +37,7 @@ __global__ __launch_bounds__(128) void lzf_decompress_paired_kernel(
     const uint32_t jid = blockIdx.x;
     if (jid >= n_jobs) return;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t role = threadIdx.x >> 6;            // 0: parser, 1: copier
+    const uint32_t role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: parser, 1: copier (uniform per wavefront)
     const lzf_decompress_job job = jobs[jid];
     const long long t_start = clock64();
 
