@@ -42,7 +42,8 @@ int ensure_device() {
 enum { kVariantAuto = -1, kVariantWave = 0, kVariantFirstBatched = 1, kVariantFirstWindowed = 100, kVariantFirstPaired = 200 };
 // Variant by name; "auto" (the default) = the producer/consumer pair kernel, with 48-byte regions while every block's
 // workgroup is resident at once (lowest latency per block: the copy stage is the critical path, the parse rides along)
-// and 24-byte regions beyond that (smaller LDS footprint, more blocks in flight).
+// and 24-byte regions beyond that (smaller LDS footprint, more blocks in flight); batches of more than eight times that
+// many blocks (small blocks, typically) go to the one-wave staged16 kernel, which has no per-block pipeline to fill.
 static int variant_by_name(const char* e) {
     if (!strcmp(e, "auto")) return kVariantAuto;
     if (!strcmp(e, "wave")) return kVariantWave;
@@ -63,13 +64,14 @@ static int variant_by_name(const char* e) {
 int decompress_variant(uint32_t n_jobs) {
     static const int v = [] { const char* e = getenv("LZF_DECOMPRESS_KERNEL"); return (e && *e) ? variant_by_name(e) : (int)kVariantAuto; }();
     if (v != kVariantAuto) return v;
-    static const int small = variant_by_name("paired48"), large = variant_by_name("paired24");
+    static const int small = variant_by_name("paired48"), large = variant_by_name("paired24"), huge = variant_by_name("staged16");
     static const uint32_t resident48 = [] {     // workgroups of the 48-byte form one device holds: 8 per CU (20 KB of LDS each)
         hipDeviceProp_t p; int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 2048u;
         return 8u * (uint32_t)p.multiProcessorCount;
     }();
-    return n_jobs <= resident48 ? small : large;
+    if (n_jobs <= resident48) return small;
+    return n_jobs <= 8u * resident48 ? large : huge;   // very many (hence small) blocks: one wave per block, no pipeline fill / drain
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

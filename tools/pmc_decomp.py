@@ -6,7 +6,7 @@ import rust_lz_fear_amd
 from rust_lz_fear_amd import device, synth
 copies = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-BS = 4 << 20
+BS = int(os.environ.get("LZF_BS", 4 << 20))
 data = synth.silesia_mix()
 d_in = torch.from_numpy(data).cuda()
 blocks = device.BlockSet(d_in, BS)
