@@ -299,7 +299,6 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
                 // (a token is at least 3 bytes, so position p only depends on positions > p):
                 //   ex[p] = exit - rend (0..253) | 254: exits further away | 255: meets a token the table cannot express
                 const uint32_t exl = ex_a + lane * kExStride;
-                const uint32_t nxl = nxt_a + lane * (uint32_t)S;
                 // per dword of nxt[]: positions 3, 2, 1 never depend on each other (a token is >= 3 bytes), position 0
                 // may depend on position 3 — two LDS round trips per four positions
 #pragma unroll 1
