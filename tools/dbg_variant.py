@@ -1,3 +1,4 @@
+"""Quick parity probe of the decompress variant LZF_DECOMPRESS_KERNEL selects (first mismatch / status per case)."""
 import os, sys
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), 'tests'))
 import numpy as np

@@ -1,3 +1,4 @@
+"""Per-block kernel cycles (and phase timers with a -DLZF_PHASE_TIMING build + LZF_PHASES=1) over the Silesia stand-in."""
 import sys, os, numpy as np, torch
 sys.path.insert(0,'/root/repo') if os.path.isdir('/root/repo') else None
 sys.path.insert(0, os.getcwd())

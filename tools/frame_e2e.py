@@ -1,11 +1,19 @@
-import os, sys, time
+"""Host-buffer frame layer timed end to end through the C ABI on one 202 MiB frame (measurement)."""
+import os, sys, time, ctypes as C
 sys.path.insert(0, os.getcwd())
 import rust_lz_fear_amd
-from rust_lz_fear_amd import framed, synth
+from rust_lz_fear_amd import framed, synth, ffi
 data = synth.silesia_mix().tobytes()
-for name, st in (("default (content checksum)", framed.CompressionSettings()), ("no content checksum", framed.CompressionSettings().content_checksum(False))):
-    framed.CompressionSettings().compress(data[:1 << 20])
-    t = time.time(); f = st.compress(data); tc = time.time() - t
-    t = time.time(); back = framed.decompress_frame(f, cap=len(data) + (8 << 20)); td = time.time() - t
-    assert back == data
-    print(f"{name}: {len(data)/2**20:.0f} MiB -> {len(f)/2**20:.0f} MiB; compress {len(data)/tc/2**30:.2f} GiB/s, decompress {len(data)/td/2**30:.2f} GiB/s (host buffers, end to end)")
+f = framed.CompressionSettings().compress(data)
+cap = len(data) + (8 << 20)
+out = C.create_string_buffer(cap); n = C.c_size_t(0); used = C.c_size_t(0)
+for it in range(3):
+    t = time.time(); rc = ffi.lib().lzf_frame_decompress(f, len(f), b"", 0, out, cap, C.byref(n), C.byref(used)); dt = time.time() - t
+    print(f"lzf_frame_decompress alone: rc {rc} {dt*1e3:.0f} ms -> {len(data)/dt/2**30:.2f} GiB/s")
+s = framed.CompressionSettings()._struct(None)
+bound = ffi.lib().lzf_frame_compress_bound(C.byref(s), len(data))
+ob = C.create_string_buffer(bound); on = C.c_size_t(0)
+for it in range(2):
+    t = time.time(); rc = ffi.lib().lzf_frame_compress(C.byref(s), data, len(data), ob, bound, C.byref(on)); dt = time.time() - t
+    print(f"lzf_frame_compress alone: rc {rc} {dt*1e3:.0f} ms -> {len(data)/dt/2**30:.2f} GiB/s")
+t = time.time(); h = ffi.lib().lzf_xxh32(data, len(data), 0); print(f"host xxh32 of the content: {(time.time()-t)*1e3:.0f} ms")

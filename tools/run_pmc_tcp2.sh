@@ -1,3 +1,4 @@
+# TA_BUSY / TD_BUSY / TCP access counters for the LZF_DBG_SKIP analysis builds dbg/lib_<variant>.so: bash tools/run_pmc_tcp2.sh variant...
 set -u
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/pmc4; cd /tmp; export TMPDIR=/tmp
 for v in "$@"; do
