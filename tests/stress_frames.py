@@ -1,5 +1,5 @@
 """Randomised frame-level parity stress (GPU frame layer vs the oracle's), not part of the test suite:
-    python tools/stress_frames.py [rounds] [seed]
+    python tests/stress_frames.py [rounds] [seed]
 Random CompressionSettings (block size, linked / independent, checksums, dictionary, content size) on random inputs:
 the GPU frame must equal the oracle's frame byte for byte, decode back to the input, and damaged frames must fail
 (or succeed) with the oracle's status."""
@@ -9,7 +9,6 @@ import numpy as np
 import oracle_ffi as o
 import rust_lz_fear_amd
 from rust_lz_fear_amd import framed, synth
-sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
 from stress_parity import make_input
 
 

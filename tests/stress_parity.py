@@ -1,5 +1,5 @@
-"""Randomised GPU-vs-oracle parity stress (not part of the test suite; run on a GPU box):
-    python tools/stress_parity.py [rounds] [seed]
+"""Randomised GPU-vs-oracle parity stress (a script next to the test suite, not collected by pytest; run on a GPU box):
+    python tests/stress_parity.py [rounds] [seed]
 Every round builds a few dozen inputs out of random pieces (text, markup, exe-like, records, 16-bit walks, noise,
 zero / motif runs of up to several 64 KiB epochs, copies of earlier pieces at random distances), compresses them on
 the GPU and with the oracle (bytes must be equal, U32 and U16 tables, cursor > 0), decompresses with the kernel variant
