@@ -49,6 +49,16 @@ def timed_launches(fn, steps):
     return evs
 
 
+def decompress_kernel_name(n_jobs):
+    """What lzf_decompress_batch launches for a batch of n_jobs (capi.hip decompress_variant; 256 CUs)."""
+    v = os.environ.get("LZF_DECOMPRESS_KERNEL", "auto")
+    if v != "auto":
+        return v
+    if n_jobs <= 2048:
+        return "lzf_decompress_paired_kernel<4096,48,640>"
+    return "lzf_decompress_paired_kernel<4096,24,384>" if n_jobs <= 16384 else "lzf_decompress_batched_kernel<4096,16,256,staged>"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -242,7 +252,7 @@ def main():
                                    (copies, float(lens.sum()) / float(clen.sum() + lens[stored_idx].sum())),
                        "blocks_per_gpu": int(nblk), "stored_blocks_per_gpu": int(len(stored_idx)),
                        "block_size": BS, "parallelism": f"block-sharded x{world}, no collective"},
-            "roofline": {"bound": "hbm", "kernel": "lzf_decompress_paired_kernel<4096,24,384>",
+            "roofline": {"bound": "hbm", "kernel": decompress_kernel_name(nk),
                          "achieved": round(d_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(d_achieved / HBM_PEAK_GBS, 5), "traffic": d_traffic,
                          "algorithmic_bytes_per_launch": d_bytes, "kernel_ms": round(d_kernel_ms, 4)},
