@@ -12,13 +12,7 @@ __global__ void lzf_decompress_batched_kernel(const lzf_decompress_job* __restri
 // LZF_DECOMPRESS_KERNEL=<name> selects one (A/B knob; every variant implements the same contract).
 #define LZF_DECOMPRESS_VARIANTS(X) \
     X(staged16, 4096, 16, 256, true)    \
-    X(staged24, 4096, 24, 384, true)    \
     X(staged32, 4096, 32, 512, true)    \
-    X(staged32r2, 2048, 32, 512, true)  \
-    X(staged48, 4096, 48, 640, true)    \
-    X(staged64, 4096, 64, 768, true)    \
-    X(staged8k64, 8192, 64, 768, true)  \
-    X(direct4, 4096, 128, 1024, false)  \
     X(direct4w, 4096, 256, 2048, false)
 #define LZF_EXT(NAME, R, S_, T, ST) extern template __global__ void lzf_decompress_batched_kernel<R, S_, T, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
 LZF_DECOMPRESS_VARIANTS(LZF_EXT)
@@ -30,13 +24,8 @@ __global__ void lzf_decompress_windowed_kernel(const lzf_decompress_job* __restr
                                                uint32_t n_jobs, uint16_t* __restrict__ scratch, uint32_t scratch_stride);
 #define LZF_WINDOWED_STRIDE(R_) ((((64u * (R_)) / 3u + 1u + 64u) + 63u) & ~63u)
 #define LZF_WINDOWED_VARIANTS(X) \
-    X(win256, 4096, 256, 64)   \
     X(win512, 4096, 512, 64)   \
-    X(win1024, 4096, 1024, 64) \
-    X(win1024w, 4096, 1024, 128) \
-    X(win512w, 4096, 512, 128) \
-    X(win1024r2, 2048, 1024, 64) \
-    X(win512r8, 8192, 512, 64)
+    X(win1024, 4096, 1024, 64)
 #define LZF_EXTW(NAME, RG, R_, W_) extern template __global__ void lzf_decompress_windowed_kernel<RG, R_, W_>(const lzf_decompress_job*, lzf_job_result*, uint32_t, uint16_t*, uint32_t);
 LZF_WINDOWED_VARIANTS(LZF_EXTW)
 #undef LZF_EXTW
@@ -46,7 +35,6 @@ __global__ void lzf_decompress_paired_kernel(const lzf_decompress_job* __restric
 #define LZF_PAIRED_VARIANTS(X) \
     X(paired16, 4096, 16, 256) \
     X(paired24, 4096, 24, 384) \
-    X(paired32, 4096, 32, 512) \
     X(paired48, 4096, 48, 640)
 #define LZF_EXTP(NAME, RG, S_, T) extern template __global__ void lzf_decompress_paired_kernel<RG, S_, T>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
 LZF_PAIRED_VARIANTS(LZF_EXTP)

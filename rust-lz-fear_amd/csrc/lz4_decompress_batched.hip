@@ -16,7 +16,7 @@
 //       fixed point is then one table lookup per lane.  Counting and recording the tokens is a
 //       hand-scheduled hop loop over nxt[] (lzf_parse_helpers.h).  Every later access to compressed
 //       bytes (token re-read, offsets, literals) is an LDS access too.
-//     STAGE = false (direct4/4w, S = 128/256): a lane walks its region hop by hop reading tokens from
+//     STAGE = false (direct4w, S = 256): a lane walks its region hop by hop reading tokens from
 //       HBM/L2 (hand-scheduled loop as well); first guesses come from a warm-up walk.
 //   A final pass records the token positions, compacted in stream order, into an LDS list.
 //

@@ -157,7 +157,7 @@ def test_decompress_overlap_offsets():
         assert e[0] == 0 and r == e
 
 
-@pytest.mark.parametrize("variant", ["wave", "staged16", "staged24", "staged32", "staged32r2", "staged48", "staged64", "staged8k64", "direct4", "direct4w", "win256", "win512", "win1024", "win512r8", "win1024w", "win512w", "paired16", "paired24", "paired32", "paired48", "auto"])
+@pytest.mark.parametrize("variant", ["auto", "wave", "staged16", "staged32", "direct4w", "win512", "win1024", "paired16", "paired24", "paired48"])
 def test_every_decompress_kernel_generation(variant):
     """Both kernel generations (and every ring/region geometry) implement the same contract."""
     import subprocess, sys
