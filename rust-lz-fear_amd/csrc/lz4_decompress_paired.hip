@@ -17,7 +17,7 @@ __global__ __launch_bounds__(128) void lzf_decompress_paired_kernel(
     const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs) {
     constexpr bool STAGE = true;
     constexpr uint32_t kMask = RING - 1;
-    constexpr uint32_t kSpanMax = RING / 4;            // output bytes one batch may produce
+    constexpr uint32_t kSpanMax = RING / 3;            // output bytes one batch may produce
     constexpr uint32_t kNearHist = RING - kSpanMax;    // history before the batch that stays intact in the ring
     constexpr uint32_t kChunk = 64u * S;               // compressed bytes whose tokens one parse covers
     constexpr uint32_t kCB = kChunk + 64u;             // staged bytes: the chunk + room for token bodies

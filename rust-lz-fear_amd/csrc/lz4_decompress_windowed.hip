@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_windowed_kernel(
     uint16_t* __restrict__ scratch, uint32_t scratch_stride) {
     constexpr uint32_t kWin = WIN;                     // bytes of a lane's window (64 or 128)
     constexpr uint32_t kMask = RING - 1;
-    constexpr uint32_t kSpanMax = RING / 4;            // output bytes one batch may produce
+    constexpr uint32_t kSpanMax = RING / 3;            // output bytes one batch may produce
     constexpr uint32_t kNearHist = RING - kSpanMax;    // history before the batch that stays intact in the ring
     constexpr uint32_t kChunk = 64u * R;               // compressed bytes whose tokens one parse covers
     constexpr uint32_t kCap = kChunk / 3u + 1u;        // most tokens a chunk can hold (a token is at least 3 bytes)
