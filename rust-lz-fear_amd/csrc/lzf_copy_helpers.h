@@ -6,16 +6,29 @@ namespace lzf {
 namespace {
 
 constexpr uint32_t kMaxPosB = 0x7FFFFF00u;
-constexpr uint32_t kShort = 32;          // bytes a lane moves by itself; longer runs are cooperative
+constexpr uint32_t kShort = 64;          // bytes a lane moves by itself (literal runs, near matches); longer runs are cooperative
+constexpr uint32_t kFarShort = 32;       // same for far matches (their bytes wait in registers while the literals are copied)
 constexpr uint32_t kTotClamp = 1u << 25; // per-sequence output clamp inside the position scan
 #ifndef LZF_DBG_SKIP
 #define LZF_DBG_SKIP 0      // analysis builds only: bit0 batches, bit1 serial matches, bit2 far, bit3 literals, bit4 flush, bit5 round 1
 #endif
 
-// Exact per-lane copy of n (1..32) bytes between two non-overlapping LDS byte ranges, neither of
-// which wraps: two-ended pieces (first/last 8, 4 or 2 bytes), at most 4 reads + 4 writes.
+// Bytes 32..n-1 of a 33..64-byte run whose first 32 bytes are moved separately: last four 8-byte pieces (they may
+// overlap the first 32 bytes: same data).
+__device__ __forceinline__ void put_tail_lds(uint32_t dst, uint32_t srca, uint32_t n) {
+    uint64_t v0, v1, v2, v3;
+    lds_ld64x4(srca + n - 32u, srca + n - 24u, srca + n - 16u, srca + n - 8u, v0, v1, v2, v3);
+    lds_st64(dst + n - 32u, v0); lds_st64(dst + n - 24u, v1); lds_st64(dst + n - 16u, v2); lds_st64(dst + n - 8u, v3);
+}
+// Exact per-lane copy of n (1..64) bytes between two non-overlapping LDS byte ranges, neither of
+// which wraps: two-ended pieces (first/last 8, 4 or 2 bytes), at most 4 reads + 4 writes up to 32 bytes, 8 + 8 beyond.
 __device__ __forceinline__ void put_small_lds(uint32_t dst, uint32_t srca, uint32_t n) {
-    if (n >= 8u) {
+    if (n > 32u) {
+        uint64_t v0, v1, v2, v3;
+        lds_ld64x4(srca, srca + 8u, srca + 16u, srca + 24u, v0, v1, v2, v3);
+        lds_st64(dst, v0); lds_st64(dst + 8u, v1); lds_st64(dst + 16u, v2); lds_st64(dst + 24u, v3);
+        put_tail_lds(dst, srca, n);
+    } else if (n >= 8u) {
         const bool big = n > 16u;
         uint64_t v0, v1, v2, v3;
         lds_ld64x4(srca, big ? srca + 8u : srca, big ? srca + n - 16u : srca, srca + n - 8u, v0, v1, v2, v3);
@@ -32,9 +45,14 @@ __device__ __forceinline__ void put_small_lds(uint32_t dst, uint32_t srca, uint3
         lds_st8(dst, lds_ld8(srca));
     }
 }
-// A match is 4..32 bytes here: two classes only.
+// A match is 4..64 bytes here: three classes.
 __device__ __forceinline__ void put_match_lds(uint32_t dst, uint32_t srca, uint32_t n) {
-    if (n >= 8u) {
+    if (n > 32u) {
+        uint64_t v0, v1, v2, v3;
+        lds_ld64x4(srca, srca + 8u, srca + 16u, srca + 24u, v0, v1, v2, v3);
+        lds_st64(dst, v0); lds_st64(dst + 8u, v1); lds_st64(dst + 16u, v2); lds_st64(dst + 24u, v3);
+        put_tail_lds(dst, srca, n);
+    } else if (n >= 8u) {
         const bool big = n > 16u;
         uint64_t v0, v1, v2, v3;
         lds_ld64x4(srca, big ? srca + 8u : srca, big ? srca + n - 16u : srca, srca + n - 8u, v0, v1, v2, v3);
@@ -48,7 +66,12 @@ __device__ __forceinline__ void put_match_lds(uint32_t dst, uint32_t srca, uint3
 }
 // Same, source in global memory (unaligned loads; reads exactly [g, g+n)).
 __device__ __forceinline__ void put_small_glb(uint32_t dst, cgu8* g, uint32_t n) {
-    if (n >= 8u) {
+    if (n > 32u) {
+        const uint64_t a0 = ld8(g), a1 = ld8(g + 8u), a2 = ld8(g + 16u), a3 = ld8(g + 24u);
+        const uint64_t b0 = ld8(g + n - 32u), b1 = ld8(g + n - 24u), b2 = ld8(g + n - 16u), b3 = ld8(g + n - 8u);
+        lds_st64(dst, a0); lds_st64(dst + 8u, a1); lds_st64(dst + 16u, a2); lds_st64(dst + 24u, a3);
+        lds_st64(dst + n - 32u, b0); lds_st64(dst + n - 24u, b1); lds_st64(dst + n - 16u, b2); lds_st64(dst + n - 8u, b3);
+    } else if (n >= 8u) {
         const bool big = n > 16u;
         const uint64_t v0 = ld8(g), v3 = ld8(g + n - 8u);
         uint64_t v1 = 0, v2 = 0;
