@@ -1,6 +1,7 @@
 // aux_kernels.hip — small kernels around the codec: XXH32 of many buffers, dictionary
 // seeding of a U32Table, EncoderTable::offset.
 #include "lzf_device.h"
+#include "kernels.h"
 
 namespace lzf {
 
@@ -90,6 +91,75 @@ __global__ __launch_bounds__(256) void lzf_copy_ranges_kernel(const uint8_t* con
     uint64_t i = a + (uint64_t)threadIdx.x * 16ull;
     for (; i + 16ull <= b; i += 256ull * 16ull) st16(d + i, ld16(s + i));
     if (i < b) for (uint64_t t = i; t < b; ++t) d[t] = s[t];     // the piece's last, partial 16 bytes (one thread)
+}
+
+// ---- job ordering for lzf_compress_batch (capi.hip) -------------------------------------------------------------------
+// A compress job's cost is not known from its size (a 4 MiB block takes 0.1 .. 0.5 s of one wavefront, depending on the
+// data), and with a few rounds of one-wave jobs the launch finishes when the last long job does.  So the batch is probed
+// first: kCostSample bytes from the middle of every large payload are compressed with the output dropped
+// (lzf_compress_compact_kernel<true>), and the real kernels then take the jobs longest first.
+__device__ __forceinline__ uint64_t cost_payload(const lzf_compress_job& j) { return j.cursor < j.input_len ? j.input_len - j.cursor : 0ull; }
+// a job is probed with `parts` pieces of `piece` bytes spread evenly over its payload (only payloads of >= 4 x that much)
+__device__ __forceinline__ uint32_t cost_sample_len(uint64_t payload, uint32_t piece, uint32_t parts) {
+    return payload >= 4ull * piece * parts ? piece * parts : 0u;
+}
+
+__global__ __launch_bounds__(256) void lzf_cost_probe_jobs_kernel(const lzf_compress_job* __restrict__ jobs,
+                                                                  lzf_compress_job* __restrict__ probes, uint32_t n,
+                                                                  uint32_t piece, uint32_t parts) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;     // probe i = piece (i % parts) of job (i / parts)
+    if (i >= n * parts) return;
+    const lzf_compress_job j = jobs[i / parts];
+    const uint64_t payload = cost_payload(j);
+    const uint32_t sl = cost_sample_len(payload, piece, parts);
+    const uint32_t k = i % parts;
+    lzf_compress_job p;
+    p.input = j.input + j.cursor + (sl ? (((payload - piece) * (2u * k + 1u) / (2u * parts)) & ~15ull) : 0ull);
+    p.input_len = sl ? piece : 0u;    // 0: small job, not probed (its estimate is its size)
+    p.cursor = 0;
+    p.out = nullptr;                  // the probe stores nothing
+    p.out_cap = ~0ull;
+    p.table = nullptr;
+    p.table_kind = LZF_TABLE_U32;
+    p.flags = 0;
+    probes[i] = p;
+}
+
+// perm = job indices by estimated cost, longest first (counting sort over 1024 cost classes; one workgroup).
+__global__ __launch_bounds__(1024) void lzf_order_by_cost_kernel(const lzf_compress_job* __restrict__ jobs,
+                                                                 const lzf_job_result* __restrict__ probe_results,
+                                                                 uint32_t* __restrict__ perm, uint32_t n,
+                                                                 uint32_t piece, uint32_t parts) {
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t max_bits;
+    const uint32_t t = threadIdx.x;
+    auto estimate = [&](uint32_t i) -> float {
+        const lzf_compress_job j = jobs[i];
+        const uint64_t payload = cost_payload(j);
+        const uint32_t sl = cost_sample_len(payload, piece, parts);
+        if (!sl) return (float)payload * 0.1f;             // not probed: ~0.1 work units (probe batches + sequences) per byte
+        uint32_t kc = 0u;                                  // probed: work units of the pieces, scaled to the payload
+        for (uint32_t k = 0; k < parts; ++k) kc += probe_results[i * parts + k].reserved;
+        return (float)kc * ((float)payload / (float)sl);
+    };
+    hist[t] = 0u;
+    if (t == 0) max_bits = 0u;
+    __syncthreads();
+    uint32_t mb = 0u;
+    for (uint32_t i = t; i < n; i += 1024u) { const uint32_t b = __float_as_uint(estimate(i)); mb = b > mb ? b : mb; }   // floats >= 0 order like their bits
+    atomicMax(&max_bits, mb);
+    __syncthreads();
+    const float top = __uint_as_float(max_bits);
+    const float scale = top > 0.f ? 1023.f / top : 0.f;
+    auto cls = [&](uint32_t i) -> uint32_t {
+        const uint32_t c = (uint32_t)(estimate(i) * scale);
+        return 1023u - (c > 1023u ? 1023u : c);          // class 0 = the longest jobs
+    };
+    for (uint32_t i = t; i < n; i += 1024u) atomicAdd(&hist[cls(i)], 1u);
+    __syncthreads();
+    if (t == 0) { uint32_t acc = 0u; for (uint32_t k = 0; k < 1024u; ++k) { const uint32_t c = hist[k]; hist[k] = acc; acc += c; } }
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += 1024u) perm[atomicAdd(&hist[cls(i)], 1u)] = i;
 }
 
 }  // namespace lzf

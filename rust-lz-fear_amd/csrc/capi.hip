@@ -61,6 +61,14 @@ static int variant_by_name(const char* e) {
 #undef LZF_NAMEP
     return kVariantAuto;                       // unknown names select the default
 }
+uint32_t cu_count() {
+    static const uint32_t n = [] {
+        hipDeviceProp_t p; int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256u;
+        return (uint32_t)p.multiProcessorCount;
+    }();
+    return n;
+}
 int decompress_variant(uint32_t n_jobs) {
     static const int v = [] { const char* e = getenv("LZF_DECOMPRESS_KERNEL"); return (e && *e) ? variant_by_name(e) : (int)kVariantAuto; }();
     if (v != kVariantAuto) return v;
@@ -103,12 +111,31 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
     // U32 jobs with a fresh or read-only template table go to the compact-table kernel (18 instead of 10 waves per CU);
     // LZF_COMPRESS_KERNEL=general keeps everything on the general kernel (A/B knob, same output).
     static const uint32_t use_compact = [] { const char* e = getenv("LZF_COMPRESS_KERNEL"); return (e && !strcmp(e, "general")) ? 0u : 1u; }();
+    // More jobs than the chip holds at once (18 one-wave jobs per CU): probe their cost and launch the longest first, or the
+    // launch ends with a few long jobs running alone (aux_kernels.hip).  LZF_COMPRESS_ORDER=natural keeps the caller's order, =always orders every batch.
+    static const uint32_t use_order = [] { const char* e = getenv("LZF_COMPRESS_ORDER"); return !e ? 1u : !strcmp(e, "natural") ? 0u : !strcmp(e, "always") ? 2u : 1u; }();
+    uint32_t* perm = nullptr;
+    void* scratch = nullptr;
+    if (use_order && use_compact && (table_kinds & LZF_KINDS_U32) && (use_order == 2u || n_jobs > 18u * cu_count())) {     // ("always": test knob)
+        const uint32_t piece = 65536u, parts = 1u;      // one 64 KiB piece from the middle of each payload (more or smaller pieces order no better)
+        const size_t n_probes = (size_t)n_jobs * parts;
+        const size_t res_off = align_up(sizeof(lzf_compress_job) * n_probes, 256);
+        const size_t perm_off = res_off + align_up(sizeof(lzf_job_result) * n_probes, 256);
+        HIP_TRY(hipMallocAsync(&scratch, perm_off + sizeof(uint32_t) * (size_t)n_jobs, st));
+        lzf_compress_job* probes = reinterpret_cast<lzf_compress_job*>(scratch);
+        lzf_job_result* pres = reinterpret_cast<lzf_job_result*>(static_cast<uint8_t*>(scratch) + res_off);
+        perm = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(scratch) + perm_off);
+        hipLaunchKernelGGL(lzf::lzf_cost_probe_jobs_kernel, dim3((uint32_t)((n_probes + 255u) / 256u)), dim3(256), 0, st, d_jobs, probes, n_jobs, piece, parts);
+        hipLaunchKernelGGL(lzf::lzf_compress_compact_kernel<true>, dim3((uint32_t)n_probes), dim3(64), 0, st, probes, pres, (uint32_t)n_probes, (const uint32_t*)nullptr);
+        hipLaunchKernelGGL(lzf::lzf_order_by_cost_kernel, dim3(1), dim3(1024), 0, st, d_jobs, pres, perm, n_jobs, piece, parts);
+    }
     if (table_kinds & LZF_KINDS_U32) {
-        if (use_compact) hipLaunchKernelGGL(lzf::lzf_compress_compact_kernel, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs);
-        hipLaunchKernelGGL(lzf::lzf_compress_wave_kernel<LZF_TABLE_U32>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, use_compact);
+        if (use_compact) hipLaunchKernelGGL(lzf::lzf_compress_compact_kernel<false>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm);
+        hipLaunchKernelGGL(lzf::lzf_compress_wave_kernel<LZF_TABLE_U32>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, use_compact, (const uint32_t*)perm);
     }
     if (table_kinds & LZF_KINDS_U16)
-        hipLaunchKernelGGL(lzf::lzf_compress_wave_kernel<LZF_TABLE_U16>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, 0u);
+        hipLaunchKernelGGL(lzf::lzf_compress_wave_kernel<LZF_TABLE_U16>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, 0u, (const uint32_t*)perm);
+    if (scratch) HIP_TRY(hipFreeAsync(scratch, st));
     HIP_TRY(hipGetLastError());
     return LZF_OK;
 }

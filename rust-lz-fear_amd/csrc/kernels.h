@@ -41,11 +41,20 @@ LZF_PAIRED_VARIANTS(LZF_EXTP)
 #undef LZF_EXTP
 template <int KIND>
 __global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
-                                         lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t skip_compact);
-extern template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U32>(const lzf_compress_job*, lzf_job_result*, uint32_t, uint32_t);
-extern template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U16>(const lzf_compress_job*, lzf_job_result*, uint32_t, uint32_t);
+                                         lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t skip_compact,
+                                         const uint32_t* __restrict__ perm);
+extern template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U32>(const lzf_compress_job*, lzf_job_result*, uint32_t, uint32_t, const uint32_t*);
+extern template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U16>(const lzf_compress_job*, lzf_job_result*, uint32_t, uint32_t, const uint32_t*);
+template <bool DRY>
 __global__ void lzf_compress_compact_kernel(const lzf_compress_job* __restrict__ jobs,
-                                            lzf_job_result* __restrict__ results, uint32_t n_jobs);
+                                            lzf_job_result* __restrict__ results, uint32_t n_jobs, const uint32_t* __restrict__ perm);
+extern template __global__ void lzf_compress_compact_kernel<false>(const lzf_compress_job*, lzf_job_result*, uint32_t, const uint32_t*);
+extern template __global__ void lzf_compress_compact_kernel<true>(const lzf_compress_job*, lzf_job_result*, uint32_t, const uint32_t*);
+// job ordering (aux_kernels.hip): cost probes of the compress jobs and the launch order derived from them
+__global__ void lzf_cost_probe_jobs_kernel(const lzf_compress_job* __restrict__ jobs, lzf_compress_job* __restrict__ probes, uint32_t n,
+                                           uint32_t piece, uint32_t parts);
+__global__ void lzf_order_by_cost_kernel(const lzf_compress_job* __restrict__ jobs, const lzf_job_result* __restrict__ probe_results,
+                                         uint32_t* __restrict__ perm, uint32_t n, uint32_t piece, uint32_t parts);
 __global__ void lzf_xxh32_kernel(const uint8_t* const* __restrict__ ptrs, const uint64_t* __restrict__ lens,
                                  uint32_t* __restrict__ out, uint32_t n);
 __global__ void lzf_copy_ranges_kernel(const uint8_t* const* __restrict__ src, uint8_t* const* __restrict__ dst,

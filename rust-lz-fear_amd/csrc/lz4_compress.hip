@@ -45,7 +45,8 @@ template <> struct TableTraits<LZF_TABLE_U16> {
 
 template <int KIND>
 __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
-    const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t skip_compact) {
+    const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t skip_compact,
+    const uint32_t* __restrict__ perm) {
     using TT = TableTraits<KIND>;
     __shared__ uint32_t tab[TT::kSlots];
 #ifdef LZF_DBG_LDS_PAD
@@ -53,8 +54,8 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
     if (threadIdx.x == 999) dbg_pad[0] = 1;
 #endif
 
-    const uint32_t jid = blockIdx.x;
-    if (jid >= n_jobs) return;
+    if (blockIdx.x >= n_jobs) return;
+    const uint32_t jid = perm ? perm[blockIdx.x] : blockIdx.x;      // launch index -> job (capi.hip: longest jobs first)
     const uint32_t lane = threadIdx.x;
     const lzf_compress_job job = jobs[jid];
     const long long t_start = clock64();
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
     }
 }
 
-template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U32>(const lzf_compress_job*, lzf_job_result*, uint32_t, uint32_t);
-template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U16>(const lzf_compress_job*, lzf_job_result*, uint32_t, uint32_t);
+template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U32>(const lzf_compress_job*, lzf_job_result*, uint32_t, uint32_t, const uint32_t*);
+template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U16>(const lzf_compress_job*, lzf_job_result*, uint32_t, uint32_t, const uint32_t*);
 
 }  // namespace lzf

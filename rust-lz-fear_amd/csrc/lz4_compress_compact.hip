@@ -28,14 +28,18 @@ constexpr uint32_t kSlots = 4096;
 __device__ __forceinline__ uint32_t hash5(uint64_t v8) { return (uint32_t)(((v8 << 24) * 889523592379ull) >> 52); }
 }  // namespace
 
+// DRY = cost probe (capi.hip, job ordering): the same parse with every store to the output dropped; only the
+// cycle count in results[].reserved is of interest.  perm (optional) maps the launch index to the job index.
+template <bool DRY>
 __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
-    const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs) {
+    const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
+    const uint32_t* __restrict__ perm) {
     __shared__ __attribute__((aligned(16))) uint32_t tab32[kSlots / 2];   // slot h = 16-bit half (h & 1) of word h >> 1
     __shared__ uint32_t par[kSlots / 32];                                 // epoch parity of slot h = bit (h & 31) of word h >> 5
     uint16_t* const tab16 = reinterpret_cast<uint16_t*>(tab32);
 
-    const uint32_t jid = blockIdx.x;
-    if (jid >= n_jobs) return;
+    if (blockIdx.x >= n_jobs) return;
+    const uint32_t jid = perm ? perm[blockIdx.x] : blockIdx.x;
     const uint32_t lane = threadIdx.x;
     const lzf_compress_job job = jobs[jid];
     const long long t_start = clock64();
@@ -43,6 +47,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
 
     cgu8* __restrict__ in = as_global(job.input);
     int status = LZF_OK;
+    uint32_t work = 0;      // DRY: probe batches + sequences, the two things a block's time is made of
 #ifdef LZF_PHASE_TIMING
     long long g_tph[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -140,6 +145,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             if (c > init && c >= 8u && (uint64_t)c + kFirstBatch + 40u <= len && (c >> 16) == swept &&
                 ((c + kFirstBatch - 1u) >> 16) == (c >> 16)) {
                 bool fast_done = true;
+                if (DRY) ++work;
                 const bool inb = lane < kFirstBatch;
                 const uint32_t ck = c + lane;
                 uint64_t A0 = 0, A1 = 0;
@@ -208,6 +214,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             }
             // ================= search: speculative batches of the :177-232 loop
             if (!found) for (;;) {
+                if (DRY) ++work;
                 { const uint32_t eb = c >> 16; if (eb != swept) sweep_to(eb); }        // the batch base enters a new 64 KiB epoch
                 // Common case, decided once per batch with scalar compares: first batch of a run, not at
                 // the block's edges.  Then every lane is a plain probe (no schedule arithmetic, no end-of-
@@ -346,10 +353,12 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     status = LZF_OUTPUT_FULL;
                     break;
                 }
-                gu8* d = s.out + s.pos;
-                if (lane == 0) d[0] = (uint8_t)((L < 15u ? L : 15u) << 4);
-                if (nl) lsic_store(d + 1, L, nl, lane);
-                wave_copy(d + 1u + nl, in + ls, L, lane);
+                if (!DRY) {
+                    gu8* d = s.out + s.pos;
+                    if (lane == 0) d[0] = (uint8_t)((L < 15u ? L : 15u) << 4);
+                    if (nl) lsic_store(d + 1, L, nl, lane);
+                    wave_copy(d + 1u + nl, in + ls, L, lane);
+                }
                 s.pos += total;
                 cursor = len;
                 break;
@@ -399,6 +408,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 }
             }
             cursor = m_pos + m;                                            // :215
+            if (DRY) ++work;
             if ((cursor >> 16) != swept) sweep_to(cursor >> 16);
             CPHASE(1);
             // The literal run is loaded first and the next run's first probes are requested right behind it, so
@@ -454,7 +464,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 if (lane == 0u) byte = (L << 4) | extra;
                 if (lane == L + 1u) byte = dup_offset;
                 if (lane == L + 2u) byte = dup_offset >> 8;
-                if (lane < total) s.out[s.pos + lane] = (uint8_t)byte;
+                if (!DRY && lane < total) s.out[s.pos + lane] = (uint8_t)byte;
                 s.pos += total;
                 CPHASE(3);
                 continue;
@@ -462,6 +472,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             const uint32_t nl = lsic_len(L), ne = lsic_len(extra);
             const uint32_t total = 1u + nl + L + 2u + ne;
             if (s.cap - s.pos < total) { status = LZF_OUTPUT_FULL; break; }
+            if (!DRY) {
             gu8* d = s.out + s.pos;
             if (lane == 0) {
                 d[0] = (uint8_t)(((L < 15u ? L : 15u) << 4) | (extra < 15u ? extra : 15u));
@@ -481,6 +492,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 wave_copy(d + 1u + nl, in + ls, L, lane);
             }
             if (ne) lsic_store(d + 3u + nl + L, extra, ne, lane);
+            }
             s.pos += total;
             CPHASE(3);
         }
@@ -491,9 +503,12 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
 #ifdef LZF_PHASE_TIMING
         { uint32_t pk = 0; for (int i = 0; i < 4; ++i) { uint32_t u = (uint32_t)(g_tph[i] >> 23); if (u > 255u) u = 255u; pk |= u << (8 * i); } results[jid].reserved = pk; }
 #else
-        results[jid].reserved = (uint32_t)((clock64() - t_start) >> 10);   // diagnostic: shader kilo-cycles spent on this job
+        results[jid].reserved = DRY ? work : (uint32_t)((clock64() - t_start) >> 10);   // diagnostic: shader kilo-cycles spent on this job
 #endif
     }
 }
+
+template __global__ void lzf_compress_compact_kernel<false>(const lzf_compress_job*, lzf_job_result*, uint32_t, const uint32_t*);
+template __global__ void lzf_compress_compact_kernel<true>(const lzf_compress_job*, lzf_job_result*, uint32_t, const uint32_t*);
 
 }  // namespace lzf

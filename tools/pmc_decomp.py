@@ -20,7 +20,7 @@ order = ok[np.argsort(-res['out_len'][ok].astype(np.int64))]
 m = len(order) * copies
 dj = np.zeros(m, dtype=device.DJOB)
 d_dec = torch.empty(m * BS, dtype=torch.uint8, device='cuda')
-idx = np.repeat(order, copies)
+idx = np.repeat(order, copies) if not os.environ.get('LZF_NOSORT') else np.tile(np.sort(order), copies)   # LZF_NOSORT: corpus order, tiled
 dj['input'] = d_out.data_ptr() + idx.astype(np.uint64) * BS
 dj['input_len'] = res['out_len'][idx]
 dj['out'] = d_dec.data_ptr() + np.arange(m, dtype=np.uint64) * BS

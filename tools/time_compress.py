@@ -13,6 +13,9 @@ j1 = blocks.compress_jobs(torch.empty(1, dtype=torch.uint8, device='cuda'), BS)
 m = n * copies
 d_out = torch.empty(m * BS, dtype=torch.uint8, device='cuda')
 cj = np.tile(j1, copies)
+if os.environ.get("LZF_ORDER"):      # analysis: jobs ordered by a per-block cost list (one number per line), longest first
+    cost = np.tile(np.loadtxt(os.environ["LZF_ORDER"]), copies)
+    cj = cj[np.argsort(-cost, kind="stable")]
 cj['out'] = d_out.data_ptr() + np.arange(m, dtype=np.uint64) * BS
 d_cj = device.to_device(cj, 'cuda'); d_res = torch.zeros(m * 16, dtype=torch.uint8, device='cuda')
 for it in range(reps):
