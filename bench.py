@@ -160,10 +160,9 @@ def main():
     dec = torch.zeros(nblk * BS, dtype=torch.uint8, device=dev)
     dec2d = dec.view(nblk, BS)
     kidx = np.nonzero(ok)[0]
-    if os.environ.get("LZF_BENCH_SORT", "1") == "1":
-        # longest-compressed-first job order: one wave per block and blocks differ ~3x in work, so the
-        # launch ends sooner when the heavy blocks are not the last ones to be dispatched (the job array
-        # order is the caller's choice; results stay indexed by job)
+    if os.environ.get("LZF_BENCH_SORT", "0") == "1":
+        # analysis knob: longest-compressed-first job array built here.  Not needed any more: lzf_decompress_batch and
+        # lzf_compress_batch order large batches on the device themselves (LZF_DECOMPRESS_ORDER / LZF_COMPRESS_ORDER).
         kidx = kidx[np.argsort(-clen[kidx].astype(np.int64), kind="stable")]
     nk = len(kidx)
     dj = np.zeros(nk, dtype=device.DJOB)

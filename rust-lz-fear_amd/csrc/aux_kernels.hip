@@ -125,23 +125,12 @@ __global__ __launch_bounds__(256) void lzf_cost_probe_jobs_kernel(const lzf_comp
     probes[i] = p;
 }
 
-// perm = job indices by estimated cost, longest first (counting sort over 1024 cost classes; one workgroup).
-__global__ __launch_bounds__(1024) void lzf_order_by_cost_kernel(const lzf_compress_job* __restrict__ jobs,
-                                                                 const lzf_job_result* __restrict__ probe_results,
-                                                                 uint32_t* __restrict__ perm, uint32_t n,
-                                                                 uint32_t piece, uint32_t parts) {
+// perm = job indices by estimate, longest first (counting sort over 1024 classes; one workgroup of 1024 threads).
+template <typename Est>
+__device__ __forceinline__ void order_longest_first(Est estimate, uint32_t* __restrict__ perm, uint32_t n) {
     __shared__ uint32_t hist[1024];
     __shared__ uint32_t max_bits;
     const uint32_t t = threadIdx.x;
-    auto estimate = [&](uint32_t i) -> float {
-        const lzf_compress_job j = jobs[i];
-        const uint64_t payload = cost_payload(j);
-        const uint32_t sl = cost_sample_len(payload, piece, parts);
-        if (!sl) return (float)payload * 0.1f;             // not probed: ~0.1 work units (probe batches + sequences) per byte
-        uint32_t kc = 0u;                                  // probed: work units of the pieces, scaled to the payload
-        for (uint32_t k = 0; k < parts; ++k) kc += probe_results[i * parts + k].reserved;
-        return (float)kc * ((float)payload / (float)sl);
-    };
     hist[t] = 0u;
     if (t == 0) max_bits = 0u;
     __syncthreads();
@@ -160,6 +149,27 @@ __global__ __launch_bounds__(1024) void lzf_order_by_cost_kernel(const lzf_compr
     if (t == 0) { uint32_t acc = 0u; for (uint32_t k = 0; k < 1024u; ++k) { const uint32_t c = hist[k]; hist[k] = acc; acc += c; } }
     __syncthreads();
     for (uint32_t i = t; i < n; i += 1024u) perm[atomicAdd(&hist[cls(i)], 1u)] = i;
+}
+
+__global__ __launch_bounds__(1024) void lzf_order_by_cost_kernel(const lzf_compress_job* __restrict__ jobs,
+                                                                 const lzf_job_result* __restrict__ probe_results,
+                                                                 uint32_t* __restrict__ perm, uint32_t n,
+                                                                 uint32_t piece, uint32_t parts) {
+    order_longest_first([&](uint32_t i) -> float {
+        const lzf_compress_job j = jobs[i];
+        const uint64_t payload = cost_payload(j);
+        const uint32_t sl = cost_sample_len(payload, piece, parts);
+        if (!sl) return (float)payload * 0.1f;             // not probed: ~0.1 work units (probe batches + sequences) per byte
+        uint32_t kc = 0u;                                  // probed: work units of the pieces, scaled to the payload
+        for (uint32_t k = 0; k < parts; ++k) kc += probe_results[i * parts + k].reserved;
+        return (float)kc * ((float)payload / (float)sl);
+    }, perm, n);
+}
+
+// Decompress jobs: the work is the parse, i.e. proportional to the compressed bytes.
+__global__ __launch_bounds__(1024) void lzf_order_by_input_len_kernel(const lzf_decompress_job* __restrict__ jobs,
+                                                                      uint32_t* __restrict__ perm, uint32_t n) {
+    order_longest_first([&](uint32_t i) -> float { return (float)jobs[i].input_len; }, perm, n);
 }
 
 }  // namespace lzf

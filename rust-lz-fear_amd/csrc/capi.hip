@@ -147,18 +147,27 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
     if (rc < 0) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const int variant = decompress_variant(n_jobs);
+    // More blocks than the chip holds at once: longest (most compressed bytes) first, so that the launch does not end with a
+    // few long jobs running alone.  LZF_DECOMPRESS_ORDER=natural keeps the caller's order, =always orders every batch.
+    static const uint32_t use_order = [] { const char* e = getenv("LZF_DECOMPRESS_ORDER"); return !e ? 1u : !strcmp(e, "natural") ? 0u : !strcmp(e, "always") ? 2u : 1u; }();
+    uint32_t* perm = nullptr;
+    if ((use_order == 2u || (use_order == 1u && n_jobs > 8u * cu_count())) && (variant < kVariantFirstWindowed || variant >= kVariantFirstPaired)) {   // (not the windowed analysis variants)
+        HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&perm), sizeof(uint32_t) * (size_t)n_jobs, st));
+        hipLaunchKernelGGL(lzf::lzf_order_by_input_len_kernel, dim3(1), dim3(1024), 0, st, d_jobs, perm, n_jobs);
+    }
+    const uint32_t* cperm = perm;
     if (variant == kVariantWave) {
-        hipLaunchKernelGGL(lzf::lzf_decompress_wave_kernel, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs);
+        hipLaunchKernelGGL(lzf::lzf_decompress_wave_kernel, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, cperm);
     } else if (variant < kVariantFirstWindowed) {
         int id = kVariantFirstBatched;
 #define LZF_LAUNCH(NAME, R, S_, T, ST) \
-        if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<R, S_, T, ST>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs);
+        if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<R, S_, T, ST>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, cperm);
         LZF_DECOMPRESS_VARIANTS(LZF_LAUNCH)
 #undef LZF_LAUNCH
     } else if (variant >= kVariantFirstPaired) {
         int id = kVariantFirstPaired;
 #define LZF_LAUNCHP(NAME, RG, S_, T) \
-        if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_paired_kernel<RG, S_, T>), dim3(n_jobs), dim3(128), 0, st, d_jobs, d_results, n_jobs);
+        if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_paired_kernel<RG, S_, T>), dim3(n_jobs), dim3(128), 0, st, d_jobs, d_results, n_jobs, cperm);
         LZF_PAIRED_VARIANTS(LZF_LAUNCHP)
 #undef LZF_LAUNCHP
     } else {
@@ -183,6 +192,7 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
         }
         HIP_TRY(hipFreeAsync(scratch, st));
     }
+    if (perm) HIP_TRY(hipFreeAsync(perm, st));
     HIP_TRY(hipGetLastError());
     return LZF_OK;
 }

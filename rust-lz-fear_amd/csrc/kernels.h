@@ -3,18 +3,19 @@
 #include "lzf_device.h"
 
 namespace lzf {
+// perm (optional, everywhere below): launch index -> job index; capi.hip launches large batches longest job first
 __global__ void lzf_decompress_wave_kernel(const lzf_decompress_job* __restrict__ jobs,
-                                           lzf_job_result* __restrict__ results, uint32_t n_jobs);
+                                           lzf_job_result* __restrict__ results, uint32_t n_jobs, const uint32_t* __restrict__ perm);
 template <int RING, int S, int TOKCAP, bool STAGE>
 __global__ void lzf_decompress_batched_kernel(const lzf_decompress_job* __restrict__ jobs,
-                                              lzf_job_result* __restrict__ results, uint32_t n_jobs);
+                                              lzf_job_result* __restrict__ results, uint32_t n_jobs, const uint32_t* __restrict__ perm);
 // Tuning variants of the batched kernel: X(name, ring bytes, region bytes, token-list entries, chunk staged in LDS).
 // LZF_DECOMPRESS_KERNEL=<name> selects one (A/B knob; every variant implements the same contract).
 #define LZF_DECOMPRESS_VARIANTS(X) \
     X(staged16, 4096, 16, 256, true)    \
     X(staged32, 4096, 32, 512, true)    \
     X(direct4w, 4096, 256, 2048, false)
-#define LZF_EXT(NAME, R, S_, T, ST) extern template __global__ void lzf_decompress_batched_kernel<R, S_, T, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+#define LZF_EXT(NAME, R, S_, T, ST) extern template __global__ void lzf_decompress_batched_kernel<R, S_, T, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*);
 LZF_DECOMPRESS_VARIANTS(LZF_EXT)
 #undef LZF_EXT
 // Third generation (lz4_decompress_windowed.hip): X(name, ring bytes, region bytes).  The token list of a chunk lives
@@ -31,12 +32,13 @@ LZF_WINDOWED_VARIANTS(LZF_EXTW)
 #undef LZF_EXTW
 // Producer / consumer pairs (lz4_decompress_paired.hip): X(name, ring bytes, region bytes, token-list entries).
 template <int RING, int S, int TOKCAP>
-__global__ void lzf_decompress_paired_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs);
+__global__ void lzf_decompress_paired_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
+                                             const uint32_t* __restrict__ perm);
 #define LZF_PAIRED_VARIANTS(X) \
     X(paired16, 4096, 16, 256) \
     X(paired24, 4096, 24, 384) \
     X(paired48, 4096, 48, 640)
-#define LZF_EXTP(NAME, RG, S_, T) extern template __global__ void lzf_decompress_paired_kernel<RG, S_, T>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+#define LZF_EXTP(NAME, RG, S_, T) extern template __global__ void lzf_decompress_paired_kernel<RG, S_, T>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*);
 LZF_PAIRED_VARIANTS(LZF_EXTP)
 #undef LZF_EXTP
 template <int KIND>
@@ -53,6 +55,7 @@ extern template __global__ void lzf_compress_compact_kernel<true>(const lzf_comp
 // job ordering (aux_kernels.hip): cost probes of the compress jobs and the launch order derived from them
 __global__ void lzf_cost_probe_jobs_kernel(const lzf_compress_job* __restrict__ jobs, lzf_compress_job* __restrict__ probes, uint32_t n,
                                            uint32_t piece, uint32_t parts);
+__global__ void lzf_order_by_input_len_kernel(const lzf_decompress_job* __restrict__ jobs, uint32_t* __restrict__ perm, uint32_t n);
 __global__ void lzf_order_by_cost_kernel(const lzf_compress_job* __restrict__ jobs, const lzf_job_result* __restrict__ probe_results,
                                          uint32_t* __restrict__ perm, uint32_t n, uint32_t piece, uint32_t parts);
 __global__ void lzf_xxh32_kernel(const uint8_t* const* __restrict__ ptrs, const uint64_t* __restrict__ lens,

@@ -54,9 +54,10 @@ struct InWindow {
 constexpr uint32_t kMaxPos = 0x7FFFFF00u;   // positions are 32-bit inside the kernel
 
 __global__ __launch_bounds__(64) void lzf_decompress_wave_kernel(
-    const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs) {
-    const uint32_t jid = blockIdx.x;
-    if (jid >= n_jobs) return;
+    const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
+    const uint32_t* __restrict__ perm) {
+    if (blockIdx.x >= n_jobs) return;
+    const uint32_t jid = perm ? perm[blockIdx.x] : blockIdx.x;
     const uint32_t lane = threadIdx.x;
     const lzf_decompress_job job = jobs[jid];
     const long long t_start = clock64();

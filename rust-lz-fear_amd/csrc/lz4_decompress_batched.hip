@@ -47,7 +47,8 @@ namespace lzf {
 
 template <int RING, int S, int TOKCAP, bool STAGE>
 __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
-    const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs) {
+    const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
+    const uint32_t* __restrict__ perm) {
     constexpr uint32_t kMask = RING - 1;
 #ifndef LZF_SPAN_DIV
 #define LZF_SPAN_DIV 3
@@ -71,8 +72,8 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
     __shared__ __attribute__((aligned(16))) uint8_t tokex[kTokBytes > kExBytes ? kTokBytes : kExBytes];
     uint16_t* const toks = reinterpret_cast<uint16_t*>(tokex);
 
-    const uint32_t jid = blockIdx.x;
-    if (jid >= n_jobs) return;
+    if (blockIdx.x >= n_jobs) return;
+    const uint32_t jid = perm ? perm[blockIdx.x] : blockIdx.x;
     const uint32_t lane = threadIdx.x;
     const lzf_decompress_job job = jobs[jid];
     const long long t_start = clock64();
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
     }
 }
 
-#define LZF_INST(NAME, R, S_, T, ST) template __global__ void lzf_decompress_batched_kernel<R, S_, T, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t);
+#define LZF_INST(NAME, R, S_, T, ST) template __global__ void lzf_decompress_batched_kernel<R, S_, T, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*);
 LZF_DECOMPRESS_VARIANTS(LZF_INST)
 #undef LZF_INST
 

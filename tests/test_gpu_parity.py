@@ -157,11 +157,12 @@ def test_decompress_overlap_offsets():
         assert e[0] == 0 and r == e
 
 
-@pytest.mark.parametrize("variant", ["auto", "wave", "staged16", "staged32", "direct4w", "win512", "win1024", "paired16", "paired24", "paired48"])
+@pytest.mark.parametrize("variant", ["auto", "wave", "staged16", "staged32", "direct4w", "win512", "win1024", "paired16", "paired24", "paired48", "ordered"])
 def test_every_decompress_kernel_generation(variant):
-    """Both kernel generations (and every ring/region geometry) implement the same contract."""
+    """Both kernel generations (and every ring/region geometry) implement the same contract.
+    "ordered": the longest-first launch order that large batches get, forced on for these small ones."""
     import subprocess, sys
-    env = dict(os.environ, LZF_DECOMPRESS_KERNEL=variant)
+    env = dict(os.environ, LZF_DECOMPRESS_KERNEL=variant) if variant != "ordered" else dict(os.environ, LZF_DECOMPRESS_ORDER="always")
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "variant_check.py")], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
