@@ -54,6 +54,19 @@ pub struct lzf_decompress_job {
 #[derive(Default, Clone, Copy)]
 pub struct lzf_job_result { pub out_len: u64, pub status: i32, pub reserved: u32 }
 
+#[repr(C)]
+#[derive(Default, Clone, Copy)]
+pub struct lzf_chain_state { pub length: u64, pub dead: u32, pub reserved: u32 }
+#[repr(C)]
+pub struct lzf_chain_step {
+    pub prev_job: u32,
+    pub job: u32,
+    pub stored_len: u64,
+    pub stored_src: *const u8,
+    pub out: *mut u8,
+    pub block_maxsize: u64,
+}
+
 extern "C" {
     pub fn lzf_abi_version() -> c_int;
     pub fn lzf_last_error() -> *const c_char;
@@ -67,6 +80,9 @@ extern "C" {
     pub fn lzf_table_seed_from_dictionary(d_table: *mut lzf_u32_table, d_dict: *const u8, dict_len: u64,
                                           hip_stream: *mut c_void) -> c_int;
     pub fn lzf_table_offset(d_table: *mut c_void, table_kind: u32, add: u64, hip_stream: *mut c_void) -> c_int;
+    pub fn lzf_table_offset_batch(d_tables: *const *mut c_void, d_adds: *const u64, n: u32, table_kind: u32, hip_stream: *mut c_void) -> c_int;
+    pub fn lzf_chain_decompress_step(d_steps: *const lzf_chain_step, d_state: *mut lzf_chain_state, n_streams: u32,
+                                     d_jobs: *mut lzf_decompress_job, d_results: *const lzf_job_result, hip_stream: *mut c_void) -> c_int;
     pub fn lzf_xxh32_batch(d_ptrs: *const *const u8, d_lens: *const u64, d_out: *mut u32, n: u32,
                            hip_stream: *mut c_void) -> c_int;
     pub fn lzf_copy_ranges(d_src: *const *const u8, d_dst: *const *mut u8, d_len: *const u64, n: u32, max_len: u64, hip_stream: *mut c_void) -> c_int;

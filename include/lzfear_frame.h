@@ -88,6 +88,18 @@ int lzf_frame_read_header(const uint8_t* in, size_t in_len, lzf_frame_info* info
 int lzf_frame_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, size_t dict_len,
                          uint8_t* out, size_t out_cap, size_t* out_len, size_t* consumed);
 
+/* Many frames per call: every block of every frame goes into the same launches and stays on the device from the
+ * first block to the last (independent-block frames: one launch; linked-block frames: block k of every stream in
+ * launch k, no host round trip in between).  Same bytes and the same per-frame statuses as one
+ * lzf_frame_compress / lzf_frame_decompress call per frame; status[f], out_len[f] (and consumed[f], may be NULL) are
+ * per frame, the return value is LZF_OK or a negative LZF_E_* (device trouble, bad arguments).  All frames of a
+ * compress call share `s` (and its dictionary), all frames of a decompress call the dictionary. */
+int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint8_t* const* in, const size_t* in_len,
+                            uint8_t* const* out, const size_t* out_cap, size_t* out_len, int* status);
+int lzf_frame_decompress_many(uint32_t n_frames, const uint8_t* const* in, const size_t* in_len,
+                              const uint8_t* dict, size_t dict_len,
+                              uint8_t* const* out, const size_t* out_cap, size_t* out_len, size_t* consumed, int* status);
+
 /* XXH32 on the host (header / content checksums; twox-hash XxHash32 in the reference). */
 uint32_t lzf_xxh32(const uint8_t* p, size_t len, uint32_t seed);
 /* Streaming form (the content hasher of a block-by-block reader, src/framed/decompress.rs:89,276-278). */

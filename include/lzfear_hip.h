@@ -135,6 +135,32 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
 int lzf_table_seed_from_dictionary(lzf_u32_table* d_table, const uint8_t* d_dict,
                                    uint64_t dict_len, void* hip_stream);
 int lzf_table_offset(void* d_table, uint32_t table_kind, uint64_t add, void* hip_stream);
+/* The same for n tables in one launch (d_tables[i]->offset += d_adds[i]): the `table.offset(forget)` of every
+ * linked-block stream of a batch between two blocks, src/framed/compress.rs:271-275. */
+int lzf_table_offset_batch(void* const* d_tables, const uint64_t* d_adds, uint32_t n, uint32_t table_kind,
+                           void* hip_stream);
+
+/* Linked-block streams decoded without a host round trip per block (src/framed/decompress.rs:238-269 for many
+ * streams at once).  A stream's output is one contiguous device buffer (history = everything decoded so far, which
+ * covers the reference's 64 KiB carry-over window); before step k this call finishes step k-1 and prepares step k of
+ * every stream:
+ *   - prev_job[i] (index into d_jobs / d_results, or UINT32_MAX): if that job failed the stream is dead (its later
+ *     jobs are emptied), else the stream's length becomes its out_len;
+ *   - job[i] (or UINT32_MAX): d_jobs[job[i]].out_existing_len = length, out_cap = length + block_maxsize + input_len,
+ *     output_limit = length + block_maxsize;
+ *   - stored_len[i] > 0: a stored block — stored_src[i] is copied to the end of the stream's output instead.
+ * d_state[i] = {length, dead flag} persists across the calls of one chain. */
+typedef struct lzf_chain_state { uint64_t length; uint32_t dead; uint32_t reserved; } lzf_chain_state;
+typedef struct lzf_chain_step {
+    uint32_t prev_job;              /* job of the previous step, UINT32_MAX if none / stored */
+    uint32_t job;                   /* job of this step, UINT32_MAX if none / stored */
+    uint64_t stored_len;            /* > 0: this step is a stored block */
+    const uint8_t* stored_src;
+    uint8_t* out;                   /* the stream's output buffer */
+    uint64_t block_maxsize;
+} lzf_chain_step;
+int lzf_chain_decompress_step(const lzf_chain_step* d_steps, lzf_chain_state* d_state, uint32_t n_streams,
+                              lzf_decompress_job* d_jobs, const lzf_job_result* d_results, void* hip_stream);
 
 /* Batched XXH32 (seed 0) of n device buffers: the per-block checksums of
  * src/framed/compress.rs:259-263 and src/framed/decompress.rs:228-235. */

@@ -76,6 +76,44 @@ __global__ void lzf_table_offset_kernel(void* table, uint32_t kind, uint64_t add
     }
 }
 
+__global__ void lzf_table_offset_batch_kernel(void* const* __restrict__ tables, const uint64_t* __restrict__ adds, uint32_t n, uint32_t kind) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !adds[i]) return;
+    if (kind == LZF_TABLE_U32) ((lzf_u32_table*)tables[i])->offset += adds[i];
+    else ((lzf_u16_table*)tables[i])->offset += adds[i];
+}
+
+// One workgroup per linked-block stream, between two decode steps (lzfear_hip.h: lzf_chain_decompress_step).
+__global__ __launch_bounds__(256) void lzf_chain_decompress_step_kernel(const lzf_chain_step* __restrict__ steps, lzf_chain_state* __restrict__ state,
+                                                                        uint32_t n, lzf_decompress_job* __restrict__ jobs,
+                                                                        const lzf_job_result* __restrict__ results) {
+    const uint32_t i = blockIdx.x;
+    if (i >= n) return;
+    const lzf_chain_step st = steps[i];
+    lzf_chain_state cs = state[i];
+    if (st.prev_job != 0xFFFFFFFFu && !cs.dead) {                 // finish the previous step (decompress.rs:253-269: the output joins the history)
+        const lzf_job_result r = results[st.prev_job];
+        if (r.status != LZF_OK) cs.dead = 1u;
+        else {
+            if (r.out_len - cs.length > st.block_maxsize) cs.dead = 1u;      // decompress.rs:272-274 BlockSizeOverflow ends the stream
+            cs.length = r.out_len;
+        }
+    }
+    if (st.job != 0xFFFFFFFFu) {
+        if (threadIdx.x == 0) {
+            lzf_decompress_job& j = jobs[st.job];
+            if (cs.dead) { j.input_len = 0; j.out_existing_len = 0; j.out_cap = 0; j.output_limit = 0; }
+            else { j.out_existing_len = cs.length; j.out_cap = cs.length + st.block_maxsize + j.input_len; j.output_limit = cs.length + st.block_maxsize; }
+        }
+    } else if (st.stored_len && !cs.dead) {                       // decompress.rs:250: a stored block is appended as it is
+        cgu8* s = as_global(st.stored_src);
+        gu8* d = as_global(st.out) + cs.length;
+        for (uint64_t t = threadIdx.x; t < st.stored_len; t += blockDim.x) d[t] = s[t];
+        cs.length += st.stored_len;
+    }
+    if (threadIdx.x == 0) state[i] = cs;
+}
+
 // Copies ranges [src[r], src[r] + len[r]) -> dst[r]: blockIdx.y = range, blockIdx.x = 64 KiB piece of it,
 // 256 threads x 16 bytes per step (unaligned 16-byte accesses are fine on gfx950).
 __global__ __launch_bounds__(256) void lzf_copy_ranges_kernel(const uint8_t* const* __restrict__ src, uint8_t* const* __restrict__ dst,

@@ -223,6 +223,27 @@ int lzf_table_offset(void* d_table, uint32_t table_kind, uint64_t add, void* hip
     return LZF_OK;
 }
 
+int lzf_table_offset_batch(void* const* d_tables, const uint64_t* d_adds, uint32_t n, uint32_t table_kind, void* hip_stream) {
+    if (n == 0) return LZF_OK;
+    if (!d_tables || !d_adds || table_kind > LZF_TABLE_U16) { g_last_error = "lzf_table_offset_batch: bad argument"; return LZF_E_INVALID; }
+    int rc = ensure_device();
+    if (rc < 0) return rc;
+    hipLaunchKernelGGL(lzf::lzf_table_offset_batch_kernel, dim3((n + 255u) / 256u), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_tables, d_adds, n, table_kind);
+    HIP_TRY(hipGetLastError());
+    return LZF_OK;
+}
+
+int lzf_chain_decompress_step(const lzf_chain_step* d_steps, lzf_chain_state* d_state, uint32_t n_streams,
+                              lzf_decompress_job* d_jobs, const lzf_job_result* d_results, void* hip_stream) {
+    if (n_streams == 0) return LZF_OK;
+    if (!d_steps || !d_state || !d_jobs || !d_results) { g_last_error = "lzf_chain_decompress_step: NULL argument"; return LZF_E_INVALID; }
+    int rc = ensure_device();
+    if (rc < 0) return rc;
+    hipLaunchKernelGGL(lzf::lzf_chain_decompress_step_kernel, dim3(n_streams), dim3(256), 0, static_cast<hipStream_t>(hip_stream), d_steps, d_state, n_streams, d_jobs, d_results);
+    HIP_TRY(hipGetLastError());
+    return LZF_OK;
+}
+
 int lzf_copy_ranges(const uint8_t* const* d_src, uint8_t* const* d_dst, const uint64_t* d_len, uint32_t n, uint64_t max_len, void* hip_stream) {
     if (n == 0 || max_len == 0) return LZF_OK;
     if (!d_src || !d_dst || !d_len) { g_last_error = "lzf_copy_ranges: NULL argument"; return LZF_E_INVALID; }

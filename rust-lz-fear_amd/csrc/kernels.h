@@ -64,4 +64,7 @@ __global__ void lzf_copy_ranges_kernel(const uint8_t* const* __restrict__ src, u
                                        const uint64_t* __restrict__ len, uint32_t n);
 __global__ void lzf_seed_table_kernel(lzf_u32_table* __restrict__ t, const uint8_t* __restrict__ dict, uint64_t dict_len);
 __global__ void lzf_table_offset_kernel(void* table, uint32_t kind, uint64_t add);
+__global__ void lzf_table_offset_batch_kernel(void* const* __restrict__ tables, const uint64_t* __restrict__ adds, uint32_t n, uint32_t kind);
+__global__ void lzf_chain_decompress_step_kernel(const lzf_chain_step* __restrict__ steps, lzf_chain_state* __restrict__ state, uint32_t n,
+                                                 lzf_decompress_job* __restrict__ jobs, const lzf_job_result* __restrict__ results);
 }  // namespace lzf

@@ -66,12 +66,13 @@ class FrameInfo(C.Structure):
 
 EXPORTS = [
     "lzf_abi_version", "lzf_last_error", "lzf_device_count", "lzf_compress_batch",
-    "lzf_decompress_batch", "lzf_table_seed_from_dictionary", "lzf_table_offset",
+    "lzf_decompress_batch", "lzf_table_seed_from_dictionary", "lzf_table_offset", "lzf_table_offset_batch",
+    "lzf_chain_decompress_step",
     "lzf_xxh32_batch", "lzf_copy_ranges", "lzf_compress_batch_host", "lzf_decompress_batch_host",
 ]
 FRAME_EXPORTS = [
     "lzf_settings_default", "lzf_frame_compress_bound", "lzf_frame_compress", "lzf_frame_read_header",
-    "lzf_frame_decompress", "lzf_xxh32", "lzf_frame_assemble",
+    "lzf_frame_decompress", "lzf_xxh32", "lzf_frame_assemble", "lzf_frame_compress_many", "lzf_frame_decompress_many",
     "lzf_xxh32_reset", "lzf_xxh32_update", "lzf_xxh32_digest",
 ]
 
@@ -117,6 +118,13 @@ def lib():
         L.lzf_frame_read_header.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(FrameInfo)]
         L.lzf_frame_decompress.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t,
                                            C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.lzf_frame_compress_many.argtypes = [C.POINTER(Settings), C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t),
+                                              C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.lzf_frame_decompress_many.argtypes = [C.c_uint32, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t,
+                                                C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t),
+                                                C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+        L.lzf_table_offset_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+        L.lzf_chain_decompress_step.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.lzf_xxh32.restype = C.c_uint32
         L.lzf_xxh32.argtypes = [C.c_char_p, C.c_size_t, C.c_uint32]
         L.lzf_xxh32_reset.argtypes = [C.POINTER(Xxh32State), C.c_uint32]

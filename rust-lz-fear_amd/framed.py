@@ -90,6 +90,31 @@ class CompressionSettings:
     def compress(self, data):                    # :137-140
         return self._run(data, None)
 
+    def compress_many(self, datas):
+        """`compress` of every buffer in `datas`, all frames through the same launches (lzf_frame_compress_many): the
+        way to keep the device busy when single frames have only a few blocks, and the only way for linked-block
+        streams (block k of every stream goes into launch k).  Returns one frame per input, byte-identical to
+        `compress(d)` of each."""
+        datas = [bytes(d) for d in datas]
+        n = len(datas)
+        if n == 0:
+            return []
+        s = self._struct(None)
+        L = ffi.lib()
+        caps = [L.lzf_frame_compress_bound(C.byref(s), len(d)) for d in datas]
+        outs = [C.create_string_buffer(max(c, 1)) for c in caps]
+        ins = (C.c_char_p * n)(*datas)
+        lens = (C.c_size_t * n)(*[len(d) for d in datas])
+        outp = (C.c_void_p * n)(*[C.cast(o, C.c_void_p) for o in outs])
+        capa = (C.c_size_t * n)(*caps)
+        olen = (C.c_size_t * n)()
+        st = (C.c_int * n)()
+        ffi.check(L.lzf_frame_compress_many(C.byref(s), n, ins, lens, outp, capa, olen, st))
+        for f in range(n):
+            if st[f] != 0:
+                raise FrameError(st[f])
+        return [outs[f].raw[: olen[f]] for f in range(n)]
+
     def compress_with_size(self, data):          # :147-157
         return self._run(data, len(data))
 
@@ -121,6 +146,29 @@ def decompress_frame(frame, dictionary=b"", cap=None):
     if rc != 0:
         raise FrameError(rc, out.raw[: n.value])
     return out.raw[: n.value]
+
+
+def decompress_frames(frames, dictionary=b"", caps=None):
+    """`decompress_frame` of every frame through the same launches (lzf_frame_decompress_many).  Returns a list of
+    (status, bytes): status 0 and the content, or the inner error kind and what the blocks before it produced —
+    exactly what `decompress_frame` returns / raises for each frame alone."""
+    frames = [bytes(f) for f in frames]
+    dictionary = bytes(dictionary)
+    n = len(frames)
+    if n == 0:
+        return []
+    if caps is None:
+        caps = [min(max(1 << 20, len(f) * 300 + (8 << 20)), 1 << 30) for f in frames]
+    outs = [C.create_string_buffer(c) for c in caps]
+    ins = (C.c_char_p * n)(*frames)
+    lens = (C.c_size_t * n)(*[len(f) for f in frames])
+    outp = (C.c_void_p * n)(*[C.cast(o, C.c_void_p) for o in outs])
+    capa = (C.c_size_t * n)(*caps)
+    olen = (C.c_size_t * n)()
+    used = (C.c_size_t * n)()
+    st = (C.c_int * n)()
+    ffi.check(ffi.lib().lzf_frame_decompress_many(n, ins, lens, dictionary, len(dictionary), outp, capa, olen, used, st))
+    return [(st[f], outs[f].raw[: olen[f]]) for f in range(n)]
 
 
 class LZ4FrameReader:

@@ -307,3 +307,63 @@ def test_config4_sharded_frame_over_rccl():
         assert framed.decompress_frame(frame) == raw
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------- many frames per call
+def _frame_inputs():
+    mix = synth.silesia_mix(20 << 20, (20 << 20) + 900_000).tobytes()
+    return [mix[:300_000], b"", mix[300_000:300_017], vectors.rng_bytes(9, 150_000), mix[100_000:760_001],
+            synth.repeat256(5 * 65536 + 1234).tobytes(), bytes(200_000), mix[:65536], mix[5:70_000]]
+
+
+@pytest.mark.parametrize("kw", [dict(block_size=64 << 10), dict(block_size=64 << 10, independent_blocks=False),
+                                dict(block_size=256 << 10, independent_blocks=False, block_checksums=True),
+                                dict(block_size=64 << 10, dictionary=synth.repeat256(65536).tobytes(), dictionary_id=7),
+                                dict(block_size=64 << 10, independent_blocks=False, dictionary=synth.silesia_mix(0, 100_000).tobytes(), dictionary_id=3),
+                                dict(block_size=64 << 10, independent_blocks=False, dictionary=b"abcd", dictionary_id=1),
+                                dict()])
+def test_compress_many_equals_one_frame_at_a_time(kw):
+    """lzf_frame_compress_many: every frame byte-identical to the oracle's frame (and so to lzf_frame_compress), in
+    independent mode (one launch for all blocks) and linked mode (block k of every stream in launch k, tables and
+    windows on the device; streams of different lengths, empty ones, stored blocks, dictionaries)."""
+    g, okw = settings_pair(**kw)
+    datas = _frame_inputs()
+    frames = g.compress_many(datas)
+    assert len(frames) == len(datas)
+    for d, f in zip(datas, frames):
+        assert f == o.frame_compress(d, o.make_settings(**okw))[1], (len(d), kw.keys())
+
+
+def test_decompress_many_equals_one_frame_at_a_time():
+    """lzf_frame_decompress_many over good and damaged frames of every flavour (independent / linked, stored blocks,
+    block checksums): the same (status, bytes) as the oracle's decoder reports for each frame alone."""
+    rng = np.random.default_rng(4242)
+    datas = _frame_inputs()
+    frames = []
+    for kw in (dict(block_size=64 << 10), dict(block_size=64 << 10, independent_blocks=False),
+               dict(block_size=64 << 10, independent_blocks=False, block_checksums=True), dict(block_size=256 << 10, content_checksum=False)):
+        for d in datas:
+            frames.append(o.frame_compress(d, o.make_settings(**kw))[1])
+    damaged = [mutate(rng, f) for f in frames for _ in range(3)]
+    allf = frames + damaged
+    got = framed.decompress_frames(allf, caps=[4 << 20] * len(allf))
+    kinds = set()
+    for f, (rc, out) in zip(allf, got):
+        erc, eout, _ = o.frame_decompress(f, cap=4 << 20)
+        assert rc == erc, (rc, erc, len(f))
+        assert out == eout
+        kinds.add(rc)
+    assert len(kinds) >= 6, kinds
+
+
+def test_many_frames_with_dictionary_roundtrip_linked():
+    """configs[4] shape, many streams in flight: 24 linked 64 KiB-block streams with the motif dictionary."""
+    d = synth.repeat256(65536).tobytes()
+    g, okw = settings_pair(block_size=64 << 10, independent_blocks=False, dictionary=d, dictionary_id=5)
+    datas = [synth.repeat256(65536 * (1 + i % 5) + 17 * i).tobytes()[i:] for i in range(24)]
+    frames = g.compress_many(datas)
+    for x, f in zip(datas, frames):
+        assert f == o.frame_compress(x, o.make_settings(**okw))[1]
+    got = framed.decompress_frames(frames, dictionary=d, caps=[1 << 20] * len(frames))
+    assert [rc for rc, _ in got] == [0] * len(frames)
+    assert [out for _, out in got] == datas
