@@ -2,9 +2,9 @@
 //
 // Mirrors lz-fear's src/framed/{compress,decompress,header}.rs; every block goes through the HIP
 // kernels via lzf_compress_batch_host / lzf_decompress_batch_host — there is no CPU codec here.
-// Independent-block frames submit all their blocks as ONE batch; linked-block frames are
-// sequential by construction (table and 64 KiB window carry, compress.rs:271-275,
-// decompress.rs:253-269) and run one block per call.
+// All blocks of all frames of a call go into the same launches (independent-block frames: one launch; linked-block
+// frames — table and 64 KiB window carry, compress.rs:271-275, decompress.rs:253-269 — one launch per block index, every
+// stream of the call advancing together); the one-frame entry points are batches of one.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
 #include <cstring>
@@ -191,80 +191,12 @@ int lzf_frame_assemble(const lzf_settings* s, uint32_t n_blocks, const uint8_t* 
     return LZF_OK;
 }
 
-// compress.rs:160-282
+// compress.rs:160-282 — one frame = a batch of one (lzf_frame_compress_many below)
 int lzf_frame_compress(const lzf_settings* s, const uint8_t* in, size_t in_len, uint8_t* out, size_t out_cap, size_t* out_len) {
     *out_len = 0;
-    uint8_t bd;
-    int rc = bd_new(s->block_size, &bd);                                       // :183
-    if (rc != LZF_OK) return rc;
-    if (out_cap < lzf_frame_compress_bound(s, in_len)) return LZF_OUT_CAPACITY;
-    const size_t bs = (size_t)s->block_size;
-    const uint8_t* dict = s->dictionary;
-    const size_t dict_len = dict ? (size_t)s->dictionary_len : 0;
-    const size_t n_blocks = (in_len + bs - 1) / bs;
-    std::vector<lzf_job_result> res(n_blocks ? n_blocks : 1);
-    std::vector<std::vector<uint8_t>> comp(n_blocks);
-    lzf_u32_table tmpl;
-    if (dict_len >= 8) { rc = seeded_template(dict, dict_len, &tmpl); if (rc != LZF_OK) return rc; }
-
-    if (s->independent_blocks) {
-        // every block is a self-contained job (prefix = dictionary, template table cloned read-only)
-        std::vector<lzf_compress_job> jobs(n_blocks);
-        std::vector<std::vector<uint8_t>> inbuf(dict_len ? n_blocks : 0);
-        std::vector<lzf_u32_table> tabs(dict_len >= 8 ? n_blocks : 0);
-        for (size_t i = 0; i < n_blocks; ++i) {
-            const size_t off = i * bs, n = in_len - off < bs ? in_len - off : bs;
-            comp[i].resize(n);
-            lzf_compress_job& j = jobs[i];
-            memset(&j, 0, sizeof j);
-            if (dict_len) {                                                    // :218,:268 in_buffer = dict ++ block
-                inbuf[i].resize(dict_len + n);
-                memcpy(inbuf[i].data(), dict, dict_len);
-                memcpy(inbuf[i].data() + dict_len, in + off, n);
-                j.input = inbuf[i].data(); j.input_len = dict_len + n; j.cursor = dict_len;
-            } else { j.input = in + off; j.input_len = n; j.cursor = 0; }
-            j.out = comp[i].data(); j.out_cap = n;                             // :242 cap = read_bytes
-            j.table_kind = LZF_TABLE_U32;                                      // :202
-            if (dict_len >= 8) { tabs[i] = tmpl; j.table = &tabs[i]; j.flags = LZF_CJOB_TABLE_READONLY; }   // :220,:270
-        }
-        rc = lzf_compress_batch_host(jobs.data(), res.data(), (uint32_t)n_blocks);
-        if (rc != LZF_OK) return rc;
-    } else {
-        // linked blocks: table + last 64 KiB carried (:271-275)
-        lzf_u32_table table;
-        if (dict_len >= 8) table = tmpl; else memset(&table, 0, sizeof table);
-        std::vector<uint8_t> in_buffer(dict, dict + dict_len);
-        for (size_t i = 0; i < n_blocks; ++i) {
-            const size_t off = i * bs, n = in_len - off < bs ? in_len - off : bs;
-            const size_t window_offset = in_buffer.size();                     // :222
-            in_buffer.insert(in_buffer.end(), in + off, in + off + n);
-            comp[i].resize(n);
-            lzf_compress_job j;
-            memset(&j, 0, sizeof j);
-            j.input = in_buffer.data(); j.input_len = in_buffer.size(); j.cursor = window_offset;
-            j.out = comp[i].data(); j.out_cap = n; j.table = &table; j.table_kind = LZF_TABLE_U32;
-            rc = lzf_compress_batch_host(&j, &res[i], 1);
-            if (rc != LZF_OK) return rc;
-            if (in_buffer.size() > LZF_WINDOW_SIZE) {
-                const size_t forget = in_buffer.size() - LZF_WINDOW_SIZE;
-                table.offset += forget;                                        // mod.rs:72-74
-                in_buffer.erase(in_buffer.begin(), in_buffer.begin() + (ptrdiff_t)forget);
-            }
-        }
-    }
-    // assemble (:244-263, :277-281)
-    std::vector<const uint8_t*> payload(n_blocks);
-    std::vector<uint32_t> clen(n_blocks), rlen(n_blocks);
-    for (size_t i = 0; i < n_blocks; ++i) {
-        const size_t off = i * bs, n = in_len - off < bs ? in_len - off : bs;
-        rlen[i] = (uint32_t)n;
-        if (res[i].status == LZF_OK) { clen[i] = (uint32_t)res[i].out_len; payload[i] = comp[i].data(); }
-        else if (res[i].status == LZF_OUTPUT_FULL) { clen[i] = UINT32_MAX; payload[i] = in + off; }   // :250-255
-        else return res[i].status;
-    }
-    uint32_t content = 0;
-    if (s->content_checksum) content = lzf_xxh32(in, in_len, 0);               // :233-235
-    return lzf_frame_assemble(s, (uint32_t)n_blocks, payload.data(), clen.data(), rlen.data(), content, out, out_cap, out_len);
+    int st = LZF_OK;
+    const int rc = lzf_frame_compress_many(s, 1, &in, &in_len, &out, &out_cap, out_len, &st);
+    return rc != LZF_OK ? rc : st;
 }
 
 // decompress.rs:102-161
@@ -291,98 +223,14 @@ int lzf_frame_read_header(const uint8_t* in, size_t in_len, lzf_frame_info* info
 #undef NEED
 }
 
-// decompress.rs:198-288
+// decompress.rs:198-288 — one frame = a batch of one (lzf_frame_decompress_many below)
 int lzf_frame_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, size_t dict_len,
                          uint8_t* out, size_t out_cap, size_t* out_len, size_t* consumed) {
     *out_len = 0; if (consumed) *consumed = 0;
-    lzf_frame_info fi;
-    int rc = lzf_frame_read_header(in, in_len, &fi);
-    if (rc != LZF_OK) { if (consumed) *consumed = rc == LZF_F_INPUT_ERROR ? in_len : 0; return rc; }
-    const size_t bmax = (size_t)fi.block_maxsize;
-    const bool linked = !(fi.flags & FL_INDEP), csum = fi.flags & FL_CSUM;
-
-    // ---- scan the block structure (u32 length hops, :205-235)
-    std::vector<Blk> blocks;
-    FrameScan sc;
-    scan_blocks(in, in_len, fi, blocks, sc);
-    const size_t r = sc.consumed;
-    const int scan_err = sc.err;
-    const bool endmark = sc.endmark; const uint32_t want_content = sc.want_content;
-    if (consumed) *consumed = r;
-
-    // ---- decode
-    const size_t nb = blocks.size();
-    std::vector<lzf_job_result> res(nb ? nb : 1);
-    std::vector<std::vector<uint8_t>> dec(nb);
-    Xxh32 content;
-    size_t w = 0;
-    int status = LZF_OK;
-    bool stopped = false;         // the io::Read adapter stops at a block that yields 0 bytes (:52-71,:286)
-    auto deliver = [&](size_t i, const uint8_t* p, size_t n) -> bool {
-        if (n > bmax) { status = LZF_F_BLOCK_SIZE_OVERFLOW; return false; }                   // :272-274
-        if (out_cap - w < n) { status = LZF_OUT_CAPACITY; return false; }
-        memcpy(out + w, p, n); w += n;
-        if (csum) content.update(p, n);                                                       // :276-278
-        if (n == 0) { stopped = true; return false; }
-        (void)i; return true;
-    };
-    if (!linked) {
-        std::vector<lzf_decompress_job> jobs; std::vector<size_t> jidx;
-        for (size_t i = 0; i < nb; ++i) {
-            if (!blocks[i].compressed) continue;
-            dec[i].resize(bmax + blocks[i].len);            // limit + C: exact malformed-input parity
-            lzf_decompress_job j;
-            memset(&j, 0, sizeof j);
-            j.input = blocks[i].data; j.input_len = blocks[i].len;
-            j.prefix = dict; j.prefix_len = dict_len;                                         // :244
-            j.out = dec[i].data(); j.out_cap = dec[i].size(); j.output_limit = bmax;          // :248
-            jobs.push_back(j); jidx.push_back(i);
-        }
-        std::vector<lzf_job_result> jr(jobs.size() ? jobs.size() : 1);
-        if (!jobs.empty()) { rc = lzf_decompress_batch_host(jobs.data(), jr.data(), (uint32_t)jobs.size()); if (rc != LZF_OK) return rc; }
-        for (size_t k = 0; k < jobs.size(); ++k) res[jidx[k]] = jr[k];
-        for (size_t i = 0; i < nb; ++i) {
-            if (blocks[i].compressed) {
-                if (res[i].status != LZF_OK) { status = res[i].status; break; }               // CodecError
-                if (!deliver(i, dec[i].data(), (size_t)res[i].out_len)) break;
-            } else if (!deliver(i, blocks[i].data, blocks[i].len)) break;                     // :250
-        }
-    } else {
-        std::vector<uint8_t> window;                                                          // carryover_window :144-148
-        std::vector<uint8_t> buf(bmax * 2 + 16);
-        for (size_t i = 0; i < nb; ++i) {
-            if (window.empty()) window.assign(dict, dict + dict_len);                         // :239-241
-            size_t n = 0; const uint8_t* p;
-            if (blocks[i].compressed) {
-                if (buf.size() < bmax + blocks[i].len) buf.resize(bmax + blocks[i].len);
-                lzf_decompress_job j;
-                memset(&j, 0, sizeof j);
-                j.input = blocks[i].data; j.input_len = blocks[i].len;
-                j.prefix = window.data(); j.prefix_len = window.size();
-                j.out = buf.data(); j.out_cap = bmax + blocks[i].len; j.output_limit = bmax;
-                lzf_job_result jr;
-                rc = lzf_decompress_batch_host(&j, &jr, 1);
-                if (rc != LZF_OK) return rc;
-                if (jr.status != LZF_OK) { status = jr.status; break; }
-                n = (size_t)jr.out_len; p = buf.data();
-            } else { n = blocks[i].len; p = blocks[i].data; }
-            // window update :253-269 (before the size check, like the reference)
-            if (n < LZF_WINDOW_SIZE) {
-                const size_t avail = window.size() + n;
-                if (avail >= LZF_WINDOW_SIZE) window.erase(window.begin(), window.begin() + (ptrdiff_t)(avail - LZF_WINDOW_SIZE));
-                window.insert(window.end(), p, p + n);
-            } else window.assign(p + n - LZF_WINDOW_SIZE, p + n);
-            if (!deliver(i, p, n)) break;
-        }
-    }
-    *out_len = w;
-    if (status != LZF_OK) return status;
-    if (stopped) return LZF_OK;
-    if (scan_err != LZF_OK) return scan_err;
-    if (endmark && csum && want_content != content.digest()) return LZF_F_FRAME_CHECKSUM_FAIL;    // :207-211
-    return LZF_OK;
+    int st = LZF_OK;
+    const int rc = lzf_frame_decompress_many(1, &in, &in_len, dict, dict_len, &out, &out_cap, out_len, consumed, &st);
+    return rc != LZF_OK ? rc : st;
 }
-
 
 // =====================================================================================================================
 // Many frames per call.  One frame of a few large blocks leaves the chip almost empty (one wavefront per block); the
