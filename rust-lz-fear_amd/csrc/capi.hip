@@ -121,13 +121,16 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
         const size_t n_probes = (size_t)n_jobs * parts;
         const size_t res_off = align_up(sizeof(lzf_compress_job) * n_probes, 256);
         const size_t perm_off = res_off + align_up(sizeof(lzf_job_result) * n_probes, 256);
-        HIP_TRY(hipMallocAsync(&scratch, perm_off + sizeof(uint32_t) * (size_t)n_jobs, st));
-        lzf_compress_job* probes = reinterpret_cast<lzf_compress_job*>(scratch);
-        lzf_job_result* pres = reinterpret_cast<lzf_job_result*>(static_cast<uint8_t*>(scratch) + res_off);
-        perm = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(scratch) + perm_off);
-        hipLaunchKernelGGL(lzf::lzf_cost_probe_jobs_kernel, dim3((uint32_t)((n_probes + 255u) / 256u)), dim3(256), 0, st, d_jobs, probes, n_jobs, piece, parts);
-        hipLaunchKernelGGL(lzf::lzf_compress_compact_kernel<true>, dim3((uint32_t)n_probes), dim3(64), 0, st, probes, pres, (uint32_t)n_probes, (const uint32_t*)nullptr);
-        hipLaunchKernelGGL(lzf::lzf_order_by_cost_kernel, dim3(1), dim3(1024), 0, st, d_jobs, pres, perm, n_jobs, piece, parts);
+        // (the order is an optimisation: without scratch memory the batch simply runs in the caller's order)
+        if (hipMallocAsync(&scratch, perm_off + sizeof(uint32_t) * (size_t)n_jobs, st) != hipSuccess) { (void)hipGetLastError(); scratch = nullptr; }
+        if (scratch) {
+            lzf_compress_job* probes = reinterpret_cast<lzf_compress_job*>(scratch);
+            lzf_job_result* pres = reinterpret_cast<lzf_job_result*>(static_cast<uint8_t*>(scratch) + res_off);
+            perm = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(scratch) + perm_off);
+            hipLaunchKernelGGL(lzf::lzf_cost_probe_jobs_kernel, dim3((uint32_t)((n_probes + 255u) / 256u)), dim3(256), 0, st, d_jobs, probes, n_jobs, piece, parts);
+            hipLaunchKernelGGL(lzf::lzf_compress_compact_kernel<true>, dim3((uint32_t)n_probes), dim3(64), 0, st, probes, pres, (uint32_t)n_probes, (const uint32_t*)nullptr);
+            hipLaunchKernelGGL(lzf::lzf_order_by_cost_kernel, dim3(1), dim3(1024), 0, st, d_jobs, pres, perm, n_jobs, piece, parts);
+        }
     }
     if (table_kinds & LZF_KINDS_U32) {
         if (use_compact) hipLaunchKernelGGL(lzf::lzf_compress_compact_kernel<false>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm);
@@ -152,8 +155,8 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
     static const uint32_t use_order = [] { const char* e = getenv("LZF_DECOMPRESS_ORDER"); return !e ? 1u : !strcmp(e, "natural") ? 0u : !strcmp(e, "always") ? 2u : 1u; }();
     uint32_t* perm = nullptr;
     if ((use_order == 2u || (use_order == 1u && n_jobs > 8u * cu_count())) && (variant < kVariantFirstWindowed || variant >= kVariantFirstPaired)) {   // (not the windowed analysis variants)
-        HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&perm), sizeof(uint32_t) * (size_t)n_jobs, st));
-        hipLaunchKernelGGL(lzf::lzf_order_by_input_len_kernel, dim3(1), dim3(1024), 0, st, d_jobs, perm, n_jobs);
+        if (hipMallocAsync(reinterpret_cast<void**>(&perm), sizeof(uint32_t) * (size_t)n_jobs, st) != hipSuccess) { (void)hipGetLastError(); perm = nullptr; }   // (then: the caller's order)
+        if (perm) hipLaunchKernelGGL(lzf::lzf_order_by_input_len_kernel, dim3(1), dim3(1024), 0, st, d_jobs, perm, n_jobs);
     }
     const uint32_t* cperm = perm;
     if (variant == kVariantWave) {
