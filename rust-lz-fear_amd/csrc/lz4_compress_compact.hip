@@ -156,39 +156,43 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 const uint32_t wi = h >> 1;
                 uint32_t oldpair = 0, pw = 0, first = lane;
                 if (inb) { oldpair = tab32[wi]; pw = par[h >> 5]; tab32[wi] = kMark; atomicMin(&tab32[wi], lane); first = tab32[wi]; }
-                if (__ballot(inb && first != lane)) {
-                    // two probes share a table word: put the words back and let the general batch sort it out
-                    if (inb) tab32[wi] = oldpair;
-                    pfA0 = A0; pfA1 = A1; pf_c = c;          // the general batch starts from the same 16 probes
-                    fast_done = false;
-                }
+                // Lanes below D (the first lane whose table word is also touched by an earlier lane) are alone in their words:
+                // their candidates are what the sequential code would see.  A winner below D makes the shared word irrelevant
+                // (lane D never commits); otherwise the words go back and the general batch sorts the collision out.
+                const uint32_t D = first_lane(__ballot(inb && first != lane));
                 uint32_t W = 64u, cand = 0; uint64_t B0 = 0, B1 = 0, PA = 0, PB = 0; bool btfast = false;
-                if (fast_done) {
-                const uint32_t s16 = (h & 1u) ? oldpair >> 16 : oldpair & 0xFFFFu;
-                const uint32_t ec = c >> 16, xk = ck & 0xFFFFu;
-                const bool same = ((pw >> (h & 31u)) & 1u) == (ec & 1u);
-                cand = ((same ? ec : ec - 1u) << 16) | s16;
-                const bool reach = inb && (same ? s16 <= xk : (ec >= 1u && s16 > xk));   // <=> cand <= ck && ck - cand <= 0xFFFF
-                btfast = cand >= 8u;
-                if (reach) {
-                    B0 = ld8(in + cand); B1 = ld8(in + cand + 8u);
-                    if (btfast) { PA = ld8(in + ck - 8u); PB = ld8(in + cand - 8u); }
-                }
-                const bool valid = reach && (uint32_t)A0 == (uint32_t)B0;  // :204-206 (m >= 4)
-                W = first_lane(__ballot(valid));
-                CPHASE(0);
-                {   // commit: lanes up to the winner (all 16 without one) write their position, the others restore their word
-                    const uint32_t last = W < 64u ? W : kFirstBatch - 1u;
-                    const uint32_t newpair = (h & 1u) ? (oldpair & 0xFFFFu) | (xk << 16) : (oldpair & 0xFFFF0000u) | xk;
-                    if (inb) tab32[wi] = lane <= last ? newpair : oldpair;
-                    if (inb && lane <= last) {
-                        const uint32_t bit = 1u << (h & 31u);
-                        if (ec & 1u) atomicOr(&par[h >> 5], bit); else atomicAnd(&par[h >> 5], ~bit);
+                {
+                    const uint32_t s16 = (h & 1u) ? oldpair >> 16 : oldpair & 0xFFFFu;
+                    const uint32_t ec = c >> 16, xk = ck & 0xFFFFu;
+                    const bool same = ((pw >> (h & 31u)) & 1u) == (ec & 1u);
+                    cand = ((same ? ec : ec - 1u) << 16) | s16;
+                    const bool reach = inb && lane < D && (same ? s16 <= xk : (ec >= 1u && s16 > xk));   // <=> cand <= ck && ck - cand <= 0xFFFF
+                    btfast = cand >= 8u;
+                    if (reach) {
+                        B0 = ld8(in + cand); B1 = ld8(in + cand + 8u);
+                        if (btfast) { PA = ld8(in + ck - 8u); PB = ld8(in + cand - 8u); }
                     }
-                    if (W >= 64u) { n = kFirstBatch; c += kFirstBatch; }   // the first 66 probes of a run advance by 1
+                    const bool valid = reach && (uint32_t)A0 == (uint32_t)B0;  // :204-206 (m >= 4)
+                    W = first_lane(__ballot(valid));
+                    CPHASE(0);
+                    if (D < 64u && W >= 64u) {
+                        if (inb) tab32[wi] = oldpair;            // (every lane read its word before any lane tagged one)
+                        pfA0 = A0; pfA1 = A1; pf_c = c;          // the general batch starts from the same 16 probes
+                        fast_done = false;
+                    } else {
+                        // commit: lanes up to the winner (all 16 without one) write their position, the others restore their
+                        // word; a shared word is written by its first lane only (the later ones lie behind the winner)
+                        const uint32_t last = W < 64u ? W : kFirstBatch - 1u;
+                        const uint32_t newpair = (h & 1u) ? (oldpair & 0xFFFFu) | (xk << 16) : (oldpair & 0xFFFF0000u) | xk;
+                        if (inb && first == lane) tab32[wi] = lane <= last ? newpair : oldpair;
+                        if (inb && lane <= last) {
+                            const uint32_t bit = 1u << (h & 31u);
+                            if (ec & 1u) atomicOr(&par[h >> 5], bit); else atomicAnd(&par[h >> 5], ~bit);
+                        }
+                        if (W >= 64u) { n = kFirstBatch; c += kFirstBatch; }   // the first 66 probes of a run advance by 1
+                    }
                 }
-                }
-                if (W < 64u) {
+                if (fast_done && W < 64u) {
                     uint32_t m_loc, bt_loc = 0;
                     {
                         const uint64_t x0 = A0 ^ B0, x1 = A1 ^ B1;
