@@ -133,7 +133,11 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
         }
     }
     if (table_kinds & LZF_KINDS_U32) {
+#ifdef LZF_DBG_DRY_MAIN      // analysis: results[].reserved = probe batches + sequences of the whole job (no output)
+        if (use_compact) hipLaunchKernelGGL(lzf::lzf_compress_compact_kernel<true>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm);
+#else
         if (use_compact) hipLaunchKernelGGL(lzf::lzf_compress_compact_kernel<false>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm);
+#endif
         hipLaunchKernelGGL(lzf::lzf_compress_wave_kernel<LZF_TABLE_U32>, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, use_compact, (const uint32_t*)perm);
     }
     if (table_kinds & LZF_KINDS_U16)

@@ -164,9 +164,16 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 {
                     const uint32_t s16 = (h & 1u) ? oldpair >> 16 : oldpair & 0xFFFFu;
                     const uint32_t ec = c >> 16, xk = ck & 0xFFFFu;
-                    const bool same = ((pw >> (h & 31u)) & 1u) == (ec & 1u);
-                    cand = ((same ? ec : ec - 1u) << 16) | s16;
-                    const bool reach = inb && lane < D && (same ? s16 <= xk : (ec >= 1u && s16 > xk));   // <=> cand <= ck && ck - cand <= 0xFFFF
+                    // (integer 0/1 arithmetic on purpose: as bools hipcc turns this into nested exec-mask control flow, ~16 scalar
+                    //  instructions, and the scalar unit is what the compress kernels run out of)
+                    const uint32_t diff = ((pw >> (h & 31u)) ^ ec) & 1u;              // 1: the slot's epoch is the previous one
+                    cand = ((ec - diff) << 16) | s16;
+                    const uint32_t e1 = ec >= 1u ? 1u : 0u, dcut = D < kFirstBatch ? D : kFirstBatch;
+                    uint32_t gt, inr;                                                     // s16 > xk; lane < dcut  (all < 2^16)
+                    asm("v_sub_u32 %0, %2, %3\n\tv_lshrrev_b32 %0, 31, %0\n\tv_sub_u32 %1, %4, %5\n\tv_lshrrev_b32 %1, 31, %1"
+                        : "=&v"(gt), "=&v"(inr) : "v"(xk), "v"(s16), "v"(lane), "s"(dcut));
+                    const uint32_t okv = ((gt & e1 & diff) | ((gt ^ 1u) & (diff ^ 1u))) & inr;   // <=> in the batch, cand <= ck && ck - cand <= 0xFFFF
+                    const bool reach = okv != 0u;
                     btfast = cand >= 8u;
                     if (reach) {
                         B0 = ld8(in + cand); B1 = ld8(in + cand + 8u);
