@@ -26,6 +26,13 @@ namespace {
 constexpr uint32_t kSlots = 4096;
 // mod.rs:41-51: v = 8 bytes LE (0 if fewer than 8 remain), ((v << 24) * 889523592379) >> 52
 __device__ __forceinline__ uint32_t hash5(uint64_t v8) { return (uint32_t)(((v8 << 24) * 889523592379ull) >> 52); }
+// a < b as 0/1 for values below 2^31 — in vector registers on purpose: the compress kernels are bound by the CU's one scalar
+// unit (hipcc keeps lane predicates as SGPR masks), so the per-sequence path does its predicate arithmetic on integers
+__device__ __forceinline__ uint32_t lt01(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_sub_u32 %0, %1, %2\n\tv_lshrrev_b32 %0, 31, %0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 }  // namespace
 
 // DRY = cost probe (capi.hip, job ordering): the same parse with every store to the output dropped; only the
@@ -109,14 +116,14 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
         uint64_t pfA0 = 0, pfA1 = 0;
         uint32_t pend_q = 0xFFFFFFFFu;      // position of a `cursor - 2` insert whose bytes (pfQ, lane 16) are in flight
         uint64_t pfQ = 0;
-        auto insert_at = [&](uint32_t q, uint64_t v8) {
-            const uint32_t h = hash5(v8);
+        auto insert_hash = [&](uint32_t q, uint32_t h) {
             if (lane == 0) {
                 tab16[h] = (uint16_t)q;
                 const uint32_t bit = 1u << (h & 31u);
                 if ((q >> 16) & 1u) atomicOr(&par[h >> 5], bit); else atomicAnd(&par[h >> 5], ~bit);
             }
         };
+        auto insert_at = [&](uint32_t q, uint64_t v8) { insert_hash(q, hash5(v8)); };
 #ifdef LZF_PHASE_TIMING
         long long tq = clock64();
 #define CPHASE(i) do { const long long tn = clock64(); g_tph[i] += tn - tq; tq = tn; } while (0)
@@ -136,7 +143,8 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             bool finished = false;   // last-literals path taken
             uint32_t m_pos = 0, m_cand = 0, m = 4u, bt = 0;
             bool more_m = false, more_bt = false;
-            uint64_t wA0 = 0, wA1 = 0;        // the winner's 16 input bytes
+            uint64_t wA0 = 0, wA1 = 0;        // the winner's 16 input bytes (general batch)
+            uint32_t ins_h = 0xFFFFFFFFu;     // fast batch: slot of the `cursor - 2` insert when its 8 bytes lie inside the winner's 16
 
             // ================= search, fast form of a run's first batch (16 probes at cursor + lane, nowhere near the
             // block's edges or an epoch boundary): most runs end here, so it is written out straight — the general batch
@@ -200,26 +208,35 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     }
                 }
                 if (fast_done && W < 64u) {
-                    uint32_t m_loc, bt_loc = 0;
-                    {
-                        const uint64_t x0 = A0 ^ B0, x1 = A1 ^ B1;
-                        m_loc = x0 ? (uint32_t)(__builtin_ctzll(x0) >> 3) : 8u + (x1 ? (uint32_t)(__builtin_ctzll(x1) >> 3) : 8u);
-                        if (btfast) { const uint64_t xp = PA ^ PB; bt_loc = xp ? (uint32_t)(__builtin_clzll(xp) >> 3) : 8u; }
-                    }
+                    // Every lane works out the match as if it were the winner — in vector registers — and the winner's packed
+                    // answer is read with one v_readlane: the scalar unit sees a handful of instructions instead of ~150.
+                    // (Here len - ck >= 56: the forward bound :195 cannot cut the 16 compared bytes, and `cursor - 2` has its 8 bytes.)
+                    const uint64_t x0 = A0 ^ B0, x1 = A1 ^ B1;
+                    const uint32_t m_loc = x0 ? (uint32_t)(__builtin_ctzll(x0) >> 3) : 8u + (x1 ? (uint32_t)(__builtin_ctzll(x1) >> 3) : 8u);   // 4..16
+                    const uint64_t xp = PA ^ PB;
+                    const uint32_t bt_loc = xp ? (uint32_t)(__builtin_clzll(xp) >> 3) : 8u;
+                    const uint32_t bf = lt01(7u, cand);                                    // btfast
+                    const uint32_t runlen = ck - ls;
+                    const uint32_t mb = runlen < cand ? runlen : cand;                     // :211-212 bounds
+                    const uint32_t btq = bt_loc < mb ? bt_loc : mb;
+                    const uint32_t bt_k = btq & (0u - bf);
+                    const uint32_t more_bt_k = (bf & (bt_loc >> 3) & lt01(8u, mb)) | ((bf ^ 1u) & lt01(0u, mb));
+                    // table.replace(input, cursor - 2) (:218): bytes [m - 2, m + 6) of the lane's 16, when they are all there (m <= 10)
+                    const uint32_t bsh = m_loc - 2u, wsel = bsh >> 2;
+                    const uint32_t d0 = (uint32_t)A0, d1 = (uint32_t)(A0 >> 32), d2 = (uint32_t)A1, d3 = (uint32_t)(A1 >> 32);
+                    const uint32_t y0 = wsel == 0u ? d0 : wsel == 1u ? d1 : d2;
+                    const uint32_t y1 = wsel == 0u ? d1 : wsel == 1u ? d2 : d3;
+                    const uint32_t y2 = wsel == 0u ? d2 : d3;
+                    const uint64_t v8 = ((uint64_t)__builtin_amdgcn_alignbyte(y2, y1, bsh & 3u) << 32) | __builtin_amdgcn_alignbyte(y1, y0, bsh & 3u);
+                    const uint32_t pk = m_loc | (bt_k << 5) | (more_bt_k << 9) | (hash5(v8) << 10);
+                    const uint32_t wpk = __builtin_amdgcn_readlane(pk, W);
                     m_pos = c + W;
                     m_cand = __builtin_amdgcn_readlane(cand, W);
-                    const uint32_t alen_w = (len - 5u) - m_pos;            // :195
-                    const uint32_t mw = __builtin_amdgcn_readlane(m_loc, W);
-                    m = mw < alen_w ? mw : alen_w;
-                    more_m = mw >= 16u && alen_w > 16u;
-                    const uint32_t runlen = m_pos - ls;
-                    const uint32_t mbw = runlen < m_cand ? runlen : m_cand;  // :211-212 bounds
-                    const uint32_t btw = __builtin_amdgcn_readlane(bt_loc, W);
-                    const bool fastw = m_cand >= 8u;
-                    bt = fastw ? (btw < mbw ? btw : mbw) : 0u;
-                    more_bt = fastw ? (btw >= 8u && mbw > 8u) : (mbw > 0u);
-                    wA0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(A0 >> 32), W) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)A0, W);
-                    wA1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(A1 >> 32), W) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)A1, W);
+                    m = wpk & 31u;
+                    more_m = m >= 16u;
+                    bt = (wpk >> 5) & 15u;
+                    more_bt = ((wpk >> 9) & 1u) != 0u;
+                    if (m <= 10u) ins_h = wpk >> 10;
                     found = true;
                 }
             }
@@ -448,18 +465,21 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             // of the next iteration, before anything reads the table — no round trip of its own.
             {
                 const uint32_t q = cursor - 2u;
-                bool now = true; uint64_t v8 = 0;
-                if (len - q >= 8u) {                                       // :43: fewer than 8 bytes left -> 0
-                    if (m - 2u + 8u <= 16u) {                              // still inside the winner's 16 bytes
-                        const uint32_t sh = (m - 2u) * 8u;
-                        v8 = sh == 0u ? wA0 : sh < 64u ? ((wA0 >> sh) | (wA1 << (64u - sh))) : (wA1 >> (sh - 64u));
-                    } else {
-                        now = false;
-                        if (lane == 16u) pfQ = ld8(in + q);
-                        pend_q = q;
+                if (ins_h != 0xFFFFFFFFu) insert_hash(q, ins_h);            // worked out by the winner's lane
+                else {
+                    bool now = true; uint64_t v8 = 0;
+                    if (len - q >= 8u) {                                       // :43: fewer than 8 bytes left -> 0
+                        if (m - 2u + 8u <= 16u) {                              // still inside the (general batch) winner's 16 bytes
+                            const uint32_t sh = (m - 2u) * 8u;
+                            v8 = sh == 0u ? wA0 : sh < 64u ? ((wA0 >> sh) | (wA1 << (64u - sh))) : (wA1 >> (sh - 64u));
+                        } else {
+                            now = false;
+                            if (lane == 16u) pfQ = ld8(in + q);
+                            pend_q = q;
+                        }
                     }
+                    if (now) insert_at(q, v8);
                 }
-                if (now) insert_at(q, v8);
             }
             const uint32_t dup_offset = m_pos - m_cand;                    // :208
             const uint32_t extra = m - 4u + bt;                            // :206,:214
