@@ -41,8 +41,12 @@ template <bool DRY>
 __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
     const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
     const uint32_t* __restrict__ perm) {
-    __shared__ __attribute__((aligned(16))) uint32_t tab32[kSlots / 2];   // slot h = 16-bit half (h & 1) of word h >> 1
-    __shared__ uint32_t par[kSlots / 32];                                 // epoch parity of slot h = bit (h & 31) of word h >> 5
+    // slot h = 16-bit half (h & 1) of word h >> 1 | epoch parity of slot h = bit (h & 31) of word kParBase + (h >> 5) | one
+    // scratch word per lane: lanes with nothing to do aim their LDS accesses there instead of leaving the instruction (exec-mask
+    // bookkeeping is scalar work, and the scalar unit is the bottleneck of this kernel)
+    constexpr uint32_t kParBase = kSlots / 2, kScratch = kSlots / 2 + kSlots / 32;
+    __shared__ __attribute__((aligned(16))) uint32_t tab32[kSlots / 2 + kSlots / 32 + kWave];
+    uint32_t* const par = tab32 + kParBase;
     uint16_t* const tab16 = reinterpret_cast<uint16_t*>(tab32);
 
     if (blockIdx.x >= n_jobs) return;
@@ -116,12 +120,12 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
         uint64_t pfA0 = 0, pfA1 = 0;
         uint32_t pend_q = 0xFFFFFFFFu;      // position of a `cursor - 2` insert whose bytes (pfQ, lane 16) are in flight
         uint64_t pfQ = 0;
-        auto insert_hash = [&](uint32_t q, uint32_t h) {
-            if (lane == 0) {
-                tab16[h] = (uint16_t)q;
-                const uint32_t bit = 1u << (h & 31u);
-                if ((q >> 16) & 1u) atomicOr(&par[h >> 5], bit); else atomicAnd(&par[h >> 5], ~bit);
-            }
+        auto insert_hash = [&](uint32_t q, uint32_t h) {       // lane 0 writes the slot, the others their scratch word
+            const uint32_t z = lane ? 1u : 0u;
+            tab16[z ? 2u * (kScratch + lane) : h] = (uint16_t)q;
+            const uint32_t pa = z ? kScratch + lane : kParBase + (h >> 5);
+            const uint32_t bit = z ? 0u : 1u << (h & 31u);
+            if ((q >> 16) & 1u) atomicOr(&tab32[pa], bit); else atomicAnd(&tab32[pa], ~bit);
         };
         auto insert_at = [&](uint32_t q, uint64_t v8) { insert_hash(q, hash5(v8)); };
 #ifdef LZF_PHASE_TIMING
@@ -161,13 +165,14 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 else if (inb) { A0 = ld8(in + ck); A1 = ld8(in + ck + 8u); }
                 pf_c = 0xFFFFFFFFu;
                 const uint32_t h = hash5(A0);
-                const uint32_t wi = h >> 1;
-                uint32_t oldpair = 0, pw = 0, first = lane;
-                if (inb) { oldpair = tab32[wi]; pw = par[h >> 5]; tab32[wi] = kMark; atomicMin(&tab32[wi], lane); first = tab32[wi]; }
+                const uint32_t wi = inb ? h >> 1 : kScratch + lane;          // (lanes outside the batch: their scratch word)
+                const uint32_t oldpair = tab32[wi], pw = par[h >> 5];
+                tab32[wi] = kMark; atomicMin(&tab32[wi], lane);
+                const uint32_t first = tab32[wi];
                 // Lanes below D (the first lane whose table word is also touched by an earlier lane) are alone in their words:
                 // their candidates are what the sequential code would see.  A winner below D makes the shared word irrelevant
                 // (lane D never commits); otherwise the words go back and the general batch sorts the collision out.
-                const uint32_t D = first_lane(__ballot(inb && first != lane));
+                const uint32_t D = first_lane(__ballot(first != lane));
                 uint32_t W = 64u, cand = 0; uint64_t B0 = 0, B1 = 0, PA = 0, PB = 0; bool btfast = false;
                 {
                     const uint32_t s16 = (h & 1u) ? oldpair >> 16 : oldpair & 0xFFFFu;
@@ -185,13 +190,13 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     btfast = cand >= 8u;
                     if (reach) {
                         B0 = ld8(in + cand); B1 = ld8(in + cand + 8u);
-                        if (btfast) { PA = ld8(in + ck - 8u); PB = ld8(in + cand - 8u); }
+                        PA = ld8(in + ck - 8u); PB = ld8(in + ((cand - 8u) & (0u - lt01(7u, cand))));   // (unused when cand < 8)
                     }
                     const bool valid = reach && (uint32_t)A0 == (uint32_t)B0;  // :204-206 (m >= 4)
                     W = first_lane(__ballot(valid));
                     CPHASE(0);
                     if (D < 64u && W >= 64u) {
-                        if (inb) tab32[wi] = oldpair;            // (every lane read its word before any lane tagged one)
+                        tab32[wi] = oldpair;                     // (every lane read its word before any lane tagged one)
                         pfA0 = A0; pfA1 = A1; pf_c = c;          // the general batch starts from the same 16 probes
                         fast_done = false;
                     } else {
@@ -199,11 +204,11 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                         // word; a shared word is written by its first lane only (the later ones lie behind the winner)
                         const uint32_t last = W < 64u ? W : kFirstBatch - 1u;
                         const uint32_t newpair = (h & 1u) ? (oldpair & 0xFFFFu) | (xk << 16) : (oldpair & 0xFFFF0000u) | xk;
-                        if (inb && first == lane) tab32[wi] = lane <= last ? newpair : oldpair;
-                        if (inb && lane <= last) {
-                            const uint32_t bit = 1u << (h & 31u);
-                            if (ec & 1u) atomicOr(&par[h >> 5], bit); else atomicAnd(&par[h >> 5], ~bit);
-                        }
+                        const uint32_t keep = lt01(lane, last + 1u);                    // lane <= last (then the lane is in the batch)
+                        tab32[first == lane ? wi : kScratch + lane] = keep ? newpair : oldpair;
+                        const uint32_t pa = keep ? kParBase + (h >> 5) : kScratch + lane;
+                        const uint32_t bit = (1u << (h & 31u)) & (0u - keep);
+                        if (ec & 1u) atomicOr(&tab32[pa], bit); else atomicAnd(&tab32[pa], ~bit);
                         if (W >= 64u) { n = kFirstBatch; c += kFirstBatch; }   // the first 66 probes of a run advance by 1
                     }
                 }
