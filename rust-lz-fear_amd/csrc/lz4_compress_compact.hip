@@ -451,7 +451,10 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             const bool lit_fast = lit_len <= 1024u;
             uint32_t lit_b = 0, lit_t = 0; u32x4 lit_v = {0, 0, 0, 0};
             if (lit_fast) {
-                if (lit_len < kWave) { if (lane >= 1u && lane <= lit_len) lit_b = in[ls + lane - 1u]; }   // lane j holds literal j-1
+                if (lit_len < kWave) {                                            // lane j holds literal j-1 (the other lanes: some literal)
+                    const uint32_t lj = lane < lit_len ? lane : lit_len;
+                    lit_b = in[ls + (lj ? lj - 1u : 0u)];                        // (ls < len: a readable byte even without literals)
+                }
                 else {
                     const uint32_t bulk = lit_len & ~15u;
                     if (lane * 16u < bulk) lit_v = ld16(in + ls + lane * 16u);
