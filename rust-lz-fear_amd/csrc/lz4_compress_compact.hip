@@ -150,18 +150,19 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             uint64_t wA0 = 0, wA1 = 0;        // the winner's 16 input bytes (general batch)
             uint32_t ins_h = 0xFFFFFFFFu;     // fast batch: slot of the `cursor - 2` insert when its 8 bytes lie inside the winner's 16
 
-            // ================= search, fast form of a run's first batch (16 probes at cursor + lane, nowhere near the
-            // block's edges or an epoch boundary): most runs end here, so it is written out straight — the general batch
-            // below does the same with schedule arithmetic, end-of-input lanes and epoch cuts
+            // ================= search, fast form for the stride-1 part of a run's schedule (its first 66 probes, mod.rs:225-231),
+            // away from the block's edges and from epoch boundaries: 16 probes at cursor + lane first — most runs end there —
+            // then up to 48 at a time.  Written out straight; the general batch below does the same with schedule arithmetic,
+            // end-of-input lanes and epoch cuts, and takes over wherever this loop stops.
             bool found = false;
-            if (c > init && c >= 8u && (uint64_t)c + kFirstBatch + 40u <= len && (c >> 16) == swept &&
-                ((c + kFirstBatch - 1u) >> 16) == (c >> 16)) {
-                bool fast_done = true;
+            while (c > init && c >= 8u && n < 58u) {
+                const uint32_t bw = n == 0u ? kFirstBatch : (66u - n < 48u ? 66u - n : 48u);
+                if (!((uint64_t)c + bw + 40u <= len && (c >> 16) == swept && ((c + bw - 1u) >> 16) == (c >> 16))) break;
                 if (DRY) ++work;
-                const bool inb = lane < kFirstBatch;
+                const bool inb = lane < bw;
                 const uint32_t ck = c + lane;
                 uint64_t A0 = 0, A1 = 0;
-                if (pf_c == c) { A0 = pfA0; A1 = pfA1; }
+                if (n == 0u && pf_c == c) { A0 = pfA0; A1 = pfA1; }
                 else if (inb) { A0 = ld8(in + ck); A1 = ld8(in + ck + 8u); }
                 pf_c = 0xFFFFFFFFu;
                 const uint32_t h = hash5(A0);
@@ -170,10 +171,11 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 tab32[wi] = kMark; atomicMin(&tab32[wi], lane);
                 const uint32_t first = tab32[wi];
                 // Lanes below D (the first lane whose table word is also touched by an earlier lane) are alone in their words:
-                // their candidates are what the sequential code would see.  A winner below D makes the shared word irrelevant
-                // (lane D never commits); otherwise the words go back and the general batch sorts the collision out.
+                // their candidates are what the sequential code would see, and their table writes are the sequential ones.  So
+                // the batch is the lanes below D: a winner among them ends the run, otherwise they commit and the next batch
+                // starts at lane D's position (D >= 1).
                 const uint32_t D = first_lane(__ballot(first != lane));
-                uint32_t W = 64u, cand = 0; uint64_t B0 = 0, B1 = 0, PA = 0, PB = 0; bool btfast = false;
+                uint32_t W = 64u, cand = 0; uint64_t B0 = 0, B1 = 0, PA = 0, PB = 0;
                 {
                     const uint32_t s16 = (h & 1u) ? oldpair >> 16 : oldpair & 0xFFFFu;
                     const uint32_t ec = c >> 16, xk = ck & 0xFFFFu;
@@ -181,13 +183,12 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     //  instructions, and the scalar unit is what the compress kernels run out of)
                     const uint32_t diff = ((pw >> (h & 31u)) ^ ec) & 1u;              // 1: the slot's epoch is the previous one
                     cand = ((ec - diff) << 16) | s16;
-                    const uint32_t e1 = ec >= 1u ? 1u : 0u, dcut = D < kFirstBatch ? D : kFirstBatch;
+                    const uint32_t e1 = ec >= 1u ? 1u : 0u, dcut = D < bw ? D : bw;
                     uint32_t gt, inr;                                                     // s16 > xk; lane < dcut  (all < 2^16)
                     asm("v_sub_u32 %0, %2, %3\n\tv_lshrrev_b32 %0, 31, %0\n\tv_sub_u32 %1, %4, %5\n\tv_lshrrev_b32 %1, 31, %1"
                         : "=&v"(gt), "=&v"(inr) : "v"(xk), "v"(s16), "v"(lane), "s"(dcut));
                     const uint32_t okv = ((gt & e1 & diff) | ((gt ^ 1u) & (diff ^ 1u))) & inr;   // <=> in the batch, cand <= ck && ck - cand <= 0xFFFF
                     const bool reach = okv != 0u;
-                    btfast = cand >= 8u;
                     if (reach) {
                         B0 = ld8(in + cand); B1 = ld8(in + cand + 8u);
                         PA = ld8(in + ck - 8u); PB = ld8(in + ((cand - 8u) & (0u - lt01(7u, cand))));   // (unused when cand < 8)
@@ -195,24 +196,20 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     const bool valid = reach && (uint32_t)A0 == (uint32_t)B0;  // :204-206 (m >= 4)
                     W = first_lane(__ballot(valid));
                     CPHASE(0);
-                    if (D < 64u && W >= 64u) {
-                        tab32[wi] = oldpair;                     // (every lane read its word before any lane tagged one)
-                        pfA0 = A0; pfA1 = A1; pf_c = c;          // the general batch starts from the same 16 probes
-                        fast_done = false;
-                    } else {
-                        // commit: lanes up to the winner (all 16 without one) write their position, the others restore their
-                        // word; a shared word is written by its first lane only (the later ones lie behind the winner)
-                        const uint32_t last = W < 64u ? W : kFirstBatch - 1u;
+                    {
+                        // commit: the lanes up to the winner, or all below the cut, write their position; the others restore their
+                        // word; a shared word is written by its first lane only (the later ones lie behind the cut)
+                        const uint32_t cut = W < 64u ? W + 1u : dcut;
                         const uint32_t newpair = (h & 1u) ? (oldpair & 0xFFFFu) | (xk << 16) : (oldpair & 0xFFFF0000u) | xk;
-                        const uint32_t keep = lt01(lane, last + 1u);                    // lane <= last (then the lane is in the batch)
+                        const uint32_t keep = lt01(lane, cut);
                         tab32[first == lane ? wi : kScratch + lane] = keep ? newpair : oldpair;
                         const uint32_t pa = keep ? kParBase + (h >> 5) : kScratch + lane;
                         const uint32_t bit = (1u << (h & 31u)) & (0u - keep);
                         if (ec & 1u) atomicOr(&tab32[pa], bit); else atomicAnd(&tab32[pa], ~bit);
-                        if (W >= 64u) { n = kFirstBatch; c += kFirstBatch; }   // the first 66 probes of a run advance by 1
+                        if (W >= 64u) { n += cut; c += cut; }                      // these probes advance by 1
                     }
                 }
-                if (fast_done && W < 64u) {
+                if (W < 64u) {
                     // Every lane works out the match as if it were the winner — in vector registers — and the winner's packed
                     // answer is read with one v_readlane: the scalar unit sees a handful of instructions instead of ~150.
                     // (Here len - ck >= 56: the forward bound :195 cannot cut the 16 compared bytes, and `cursor - 2` has its 8 bytes.)
@@ -243,6 +240,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     more_bt = ((wpk >> 9) & 1u) != 0u;
                     if (m <= 10u) ins_h = wpk >> 10;
                     found = true;
+                    break;
                 }
             }
             // ================= search: speculative batches of the :177-232 loop
