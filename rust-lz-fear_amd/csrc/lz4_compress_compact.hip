@@ -48,6 +48,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
     __shared__ __attribute__((aligned(16))) uint32_t tab32[kSlots / 2 + kSlots / 32 + kWave];
     uint32_t* const par = tab32 + kParBase;
     uint16_t* const tab16 = reinterpret_cast<uint16_t*>(tab32);
+    const uint32_t tab_a = lds_addr(tab32);
 
     if (blockIdx.x >= n_jobs) return;
     const uint32_t jid = perm ? perm[blockIdx.x] : blockIdx.x;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             tab16[z ? 2u * (kScratch + lane) : h] = (uint16_t)q;
             const uint32_t pa = z ? kScratch + lane : kParBase + (h >> 5);
             const uint32_t bit = z ? 0u : 1u << (h & 31u);
-            if ((q >> 16) & 1u) atomicOr(&tab32[pa], bit); else atomicAnd(&tab32[pa], ~bit);
+            lds_mskor32(tab_a + 4u * pa, bit, bit & (0u - ((q >> 16) & 1u)));      // the slot's parity bit := parity of q's epoch
         };
         auto insert_at = [&](uint32_t q, uint64_t v8) { insert_hash(q, hash5(v8)); };
 #ifdef LZF_PHASE_TIMING
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                         tab32[first == lane ? wi : kScratch + lane] = keep ? newpair : oldpair;
                         const uint32_t pa = keep ? kParBase + (h >> 5) : kScratch + lane;
                         const uint32_t bit = (1u << (h & 31u)) & (0u - keep);
-                        if (ec & 1u) atomicOr(&tab32[pa], bit); else atomicAnd(&tab32[pa], ~bit);
+                        lds_mskor32(tab_a + 4u * pa, bit, bit & (0u - (ec & 1u)));
                         if (W >= 64u) { n += cut; c += cut; }                      // these probes advance by 1
                     }
                 }
@@ -346,7 +347,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     if (dwrites) tab16[h] = (uint16_t)xk;
                     if (commits || dwrites) {
                         const uint32_t bit = 1u << (h & 31u);
-                        if ((c >> 16) & 1u) atomicOr(&par[h >> 5], bit); else atomicAnd(&par[h >> 5], ~bit);
+                        lds_mskor32(tab_a + 4u * (kParBase + (h >> 5)), bit, bit & (0u - ((c >> 16) & 1u)));
                     }
                 }
                 if (status != LZF_OK) break;

@@ -94,6 +94,9 @@ __device__ __forceinline__ uint32_t wave_prev(uint32_t v, uint32_t first) {
 // their own data (s_waitcnt lgkmcnt(0)) because hipcc does not count asm memory operations.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)reinterpret_cast<uintptr_t>(p); }
+// mem = (mem & ~mask) | val in one LDS instruction (no branch on "set or clear", no return value to wait for; LDS executes a
+// wave's accesses in order, so later reads see it)
+__device__ __forceinline__ void lds_mskor32(uint32_t a, uint32_t mask, uint32_t val) { asm volatile("ds_mskor_b32 %0, %1, %2" ::"v"(a), "v"(mask), "v"(val) : "memory"); }
 __device__ __forceinline__ void lds_st8(uint32_t a, uint32_t v) { asm volatile("ds_write_b8 %0, %1" ::"v"(a), "v"(v) : "memory"); }
 __device__ __forceinline__ void lds_st16(uint32_t a, uint32_t v) { asm volatile("ds_write_b16 %0, %1" ::"v"(a), "v"(v) : "memory"); }
 __device__ __forceinline__ void lds_st32(uint32_t a, uint32_t v) { asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory"); }
