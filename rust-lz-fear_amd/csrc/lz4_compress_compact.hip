@@ -68,6 +68,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
         const uint32_t len = (uint32_t)job.input_len;
         const uint32_t init = (uint32_t)job.cursor;                      // :169
         uint32_t cursor = init;
+        const uint32_t fast_lo = init + 1u > 8u ? init + 1u : 8u;       // the fast search wants c > init (:200) and 8 bytes before c
         uint32_t swept = init >> 16;                                     // epoch the table is consistent with
         // ---- table in: Default::default() (:32-36) or the caller's read-only template, converted
         {
@@ -156,9 +157,9 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             // then up to 48 at a time.  Written out straight; the general batch below does the same with schedule arithmetic,
             // end-of-input lanes and epoch cuts, and takes over wherever this loop stops.
             bool found = false;
-            while (c > init && c >= 8u && n < 58u) {
+            while (c >= fast_lo && n < 58u) {
                 const uint32_t bw = n == 0u ? kFirstBatch : (66u - n < 48u ? 66u - n : 48u);
-                if (!((uint64_t)c + bw + 40u <= len && (c >> 16) == swept && ((c + bw - 1u) >> 16) == (c >> 16))) break;
+                if (!(c + bw + 40u <= len && (c >> 16) == swept && ((c + bw - 1u) >> 16) == (c >> 16))) break;   // (len < 2^31: no wrap)
                 if (DRY) ++work;
                 const bool inb = lane < bw;
                 const uint32_t ck = c + lane;
@@ -251,7 +252,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 // Common case, decided once per batch with scalar compares: first batch of a run, not at
                 // the block's edges.  Then every lane is a plain probe (no schedule arithmetic, no end-of-
                 // input lanes, full 16-byte loads in range, positions fit the slot type).
-                const bool easy = n == 0u && c > init && c >= 8u && (uint64_t)c + kFirstBatch + 40u <= len &&
+                const bool easy = n == 0u && c > init && c >= 8u && c + kFirstBatch + 40u <= len &&
                                   ((c + kFirstBatch - 1u) >> 16) == (c >> 16);          // and the batch stays inside one epoch
                 // probe positions: the first 66 probes of a run advance by 1 (mod.rs:225-231)
                 uint32_t ck, sn = 0;
@@ -463,7 +464,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             {
                 const uint32_t ckn = cursor + lane;
                 pfA0 = 0; pfA1 = 0;
-                if ((uint64_t)cursor + kFirstBatch + 40u <= len) { if (lane < kFirstBatch) { pfA0 = ld8(in + ckn); pfA1 = ld8(in + ckn + 8u); } }
+                if (cursor + kFirstBatch + 40u <= len) { if (lane < kFirstBatch) { pfA0 = ld8(in + ckn); pfA1 = ld8(in + ckn + 8u); } }
                 else if (lane < kFirstBatch && ckn <= len && len - ckn >= 12u) { pfA0 = ld8(in + ckn); pfA1 = ld8_part(ckn + 8u); }
                 pf_c = cursor;
             }
