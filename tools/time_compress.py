@@ -10,6 +10,8 @@ data = synth.silesia_mix()
 d_in = torch.from_numpy(data).cuda()
 blocks = device.BlockSet(d_in, BS); n = blocks.n
 j1 = blocks.compress_jobs(torch.empty(1, dtype=torch.uint8, device='cuda'), BS)
+if os.environ.get("LZF_ONLY_BLOCK"):     # analysis: tile one block of the corpus only (e.g. counters of a pure-text block)
+    j1 = j1[int(os.environ["LZF_ONLY_BLOCK"]):][:1]; n = 1
 m = n * copies
 d_out = torch.empty(m * BS, dtype=torch.uint8, device='cuda')
 cj = np.tile(j1, copies)
