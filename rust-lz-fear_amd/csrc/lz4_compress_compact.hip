@@ -24,6 +24,7 @@ namespace lzf {
 
 namespace {
 constexpr uint32_t kSlots = 4096;
+constexpr uint32_t kProbeLanes = 32;     // lanes that fetch 16 input bytes for a run's first batch: its 16 probes and 16 positions behind them
 // mod.rs:41-51: v = 8 bytes LE (0 if fewer than 8 remain), ((v << 24) * 889523592379) >> 52
 __device__ __forceinline__ uint32_t hash5(uint64_t v8) { return (uint32_t)(((v8 << 24) * 889523592379ull) >> 52); }
 // a < b as 0/1 for values below 2^31 — in vector registers on purpose: the compress kernels are bound by the CU's one scalar
@@ -149,7 +150,8 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             bool finished = false;   // last-literals path taken
             uint32_t m_pos = 0, m_cand = 0, m = 4u, bt = 0;
             bool more_m = false, more_bt = false;
-            uint64_t wA0 = 0, wA1 = 0;        // the winner's 16 input bytes (general batch)
+            uint64_t wA0 = 0, wA1 = 0;        // the winner's 16 input bytes (general batch only: wA_valid)
+            bool wA_valid = false;
             uint32_t ins_h = 0xFFFFFFFFu;     // fast batch: slot of the `cursor - 2` insert when its 8 bytes lie inside the winner's 16
 
             // ================= search, fast form for the stride-1 part of a run's schedule (its first 66 probes, mod.rs:225-231),
@@ -163,9 +165,10 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 if (DRY) ++work;
                 const bool inb = lane < bw;
                 const uint32_t ck = c + lane;
+                const uint32_t have = bw > kProbeLanes ? bw : kProbeLanes;   // lanes holding 16 input bytes (c + 40 + bw <= len: readable)
                 uint64_t A0 = 0, A1 = 0;
                 if (n == 0u && pf_c == c) { A0 = pfA0; A1 = pfA1; }
-                else if (inb) { A0 = ld8(in + ck); A1 = ld8(in + ck + 8u); }
+                else if (lane < have) { A0 = ld8(in + ck); A1 = ld8(in + ck + 8u); }
                 pf_c = 0xFFFFFFFFu;
                 const uint32_t h = hash5(A0);
                 const uint32_t wi = inb ? h >> 1 : kScratch + lane;          // (lanes outside the batch: their scratch word)
@@ -225,14 +228,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     const uint32_t btq = bt_loc < mb ? bt_loc : mb;
                     const uint32_t bt_k = btq & (0u - bf);
                     const uint32_t more_bt_k = (bf & (bt_loc >> 3) & lt01(8u, mb)) | ((bf ^ 1u) & lt01(0u, mb));
-                    // table.replace(input, cursor - 2) (:218): bytes [m - 2, m + 6) of the lane's 16, when they are all there (m <= 10)
-                    const uint32_t bsh = m_loc - 2u, wsel = bsh >> 2;
-                    const uint32_t d0 = (uint32_t)A0, d1 = (uint32_t)(A0 >> 32), d2 = (uint32_t)A1, d3 = (uint32_t)(A1 >> 32);
-                    const uint32_t y0 = wsel == 0u ? d0 : wsel == 1u ? d1 : d2;
-                    const uint32_t y1 = wsel == 0u ? d1 : wsel == 1u ? d2 : d3;
-                    const uint32_t y2 = wsel == 0u ? d2 : d3;
-                    const uint64_t v8 = ((uint64_t)__builtin_amdgcn_alignbyte(y2, y1, bsh & 3u) << 32) | __builtin_amdgcn_alignbyte(y1, y0, bsh & 3u);
-                    const uint32_t pk = m_loc | (bt_k << 5) | (more_bt_k << 9) | (hash5(v8) << 10);
+                    const uint32_t pk = m_loc | (bt_k << 5) | (more_bt_k << 9);
                     const uint32_t wpk = __builtin_amdgcn_readlane(pk, W);
                     m_pos = c + W;
                     m_cand = __builtin_amdgcn_readlane(cand, W);
@@ -240,7 +236,10 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     more_m = m >= 16u;
                     bt = (wpk >> 5) & 15u;
                     more_bt = ((wpk >> 9) & 1u) != 0u;
-                    if (m <= 10u) ins_h = wpk >> 10;
+                    // table.replace(input, cursor - 2) (:218): the 8 bytes at cursor - 2 are the probe bytes of lane W + m - 2, whose
+                    // hash is already there (lanes up to `have` hold probe bytes; an extended match is handled at the insert)
+                    const uint32_t qi = W + m - 2u;
+                    if (!more_m && qi < have) ins_h = __builtin_amdgcn_readlane(h, qi);
                     found = true;
                     break;
                 }
@@ -366,6 +365,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     more_bt = fastw ? (btw >= 8u && mbw > 8u) : (mbw > 0u);
                     wA0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(A0 >> 32), W) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)A0, W);
                     wA1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((uint32_t)(A1 >> 32), W) << 32) | (uint32_t)__builtin_amdgcn_readlane((uint32_t)A1, W);
+                    wA_valid = true;
                     break;
                 }
                 if (outcome == 2) { finished = true; break; }
@@ -464,7 +464,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             {
                 const uint32_t ckn = cursor + lane;
                 pfA0 = 0; pfA1 = 0;
-                if (cursor + kFirstBatch + 40u <= len) { if (lane < kFirstBatch) { pfA0 = ld8(in + ckn); pfA1 = ld8(in + ckn + 8u); } }
+                if (cursor + kFirstBatch + 40u <= len) { if (lane < kProbeLanes) { pfA0 = ld8(in + ckn); pfA1 = ld8(in + ckn + 8u); } }   // (16 probes + the bytes behind them)
                 else if (lane < kFirstBatch && ckn <= len && len - ckn >= 12u) { pfA0 = ld8(in + ckn); pfA1 = ld8_part(ckn + 8u); }
                 pf_c = cursor;
             }
@@ -477,7 +477,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 else {
                     bool now = true; uint64_t v8 = 0;
                     if (len - q >= 8u) {                                       // :43: fewer than 8 bytes left -> 0
-                        if (m - 2u + 8u <= 16u) {                              // still inside the (general batch) winner's 16 bytes
+                        if (wA_valid && m - 2u + 8u <= 16u) {                              // still inside the (general batch) winner's 16 bytes
                             const uint32_t sh = (m - 2u) * 8u;
                             v8 = sh == 0u ? wA0 : sh < 64u ? ((wA0 >> sh) | (wA1 << (64u - sh))) : (wA1 >> (sh - 64u));
                         } else {
