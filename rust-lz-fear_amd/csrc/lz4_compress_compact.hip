@@ -152,6 +152,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             bool more_m = false, more_bt = false;
             uint64_t wA0 = 0, wA1 = 0;        // the winner's 16 input bytes (general batch only: wA_valid)
             bool wA_valid = false;
+            bool straight = false;            // the whole sequence was handled inside the fast search
             uint32_t ins_h = 0xFFFFFFFFu;     // fast batch: slot of the `cursor - 2` insert when its 8 bytes lie inside the winner's 16
 
             // ================= search, fast form for the stride-1 part of a run's schedule (its first 66 probes, mod.rs:225-231),
@@ -241,9 +242,33 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     const uint32_t qi = W + m - 2u;
                     if (!more_m && qi < have) ins_h = __builtin_amdgcn_readlane(h, qi);
                     found = true;
+                    // The common sequence in one straight line (everything the general tail below decides with a branch each is
+                    // known here): no extension, no epoch change, <= 14 literals, match length in the token, room in the sink.
+                    {
+                        const uint32_t cur2 = m_pos + m, ex2 = m - 4u + bt, L2 = (m_pos - bt) - ls;
+                        if (ins_h != 0xFFFFFFFFu && !more_bt && (cur2 >> 16) == swept && cur2 + kFirstBatch + 40u <= len &&
+                            (L2 > ex2 ? L2 : ex2) < 15u && s.cap - s.pos >= L2 + 3u) {
+                            if (DRY) ++work;
+                            cursor = cur2;                                                 // :215
+                            const uint32_t lj = lane < L2 ? lane : L2;
+                            uint32_t byte = in[ls + (lj ? lj - 1u : 0u)];                // lane j: literal j-1
+                            pfA0 = 0; pfA1 = 0;                                            // the next run's probe bytes, right behind
+                            if (lane < kProbeLanes) { pfA0 = ld8(in + cur2 + lane); pfA1 = ld8(in + cur2 + lane + 8u); }
+                            pf_c = cur2;
+                            insert_hash(cur2 - 2u, ins_h);                                 // :218
+                            const uint32_t off2 = m_pos - m_cand;                          // :208
+                            if (lane == 0u) byte = (L2 << 4) | ex2;                        // write_group, :150-163
+                            if (lane == L2 + 1u) byte = off2;
+                            if (lane == L2 + 2u) byte = off2 >> 8;
+                            if (!DRY && lane < L2 + 3u) s.out[s.pos + lane] = (uint8_t)byte;
+                            s.pos += L2 + 3u;
+                            straight = true;
+                        }
+                    }
                     break;
                 }
             }
+            if (straight) continue;
             // ================= search: speculative batches of the :177-232 loop
             if (!found) for (;;) {
                 if (DRY) ++work;
