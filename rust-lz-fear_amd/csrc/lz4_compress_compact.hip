@@ -70,6 +70,9 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
         const uint32_t init = (uint32_t)job.cursor;                      // :169
         uint32_t cursor = init;
         const uint32_t fast_lo = init + 1u > 8u ? init + 1u : 8u;       // the fast search wants c > init (:200) and 8 bytes before c
+        // ... and a batch of bw probes at c inside the swept epoch with 40 readable bytes behind it: f_lo <= c && c + bw <= f_hi
+        // (two scalar compares per batch; recomputed when the epoch changes)
+        uint32_t f_lo = 0xFFFFFFFFu, f_hi = 0u;
         uint32_t swept = init >> 16;                                     // epoch the table is consistent with
         // ---- table in: Default::default() (:32-36) or the caller's read-only template, converted
         {
@@ -90,6 +93,12 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 for (uint32_t i = lane; i < kSlots / 32; i += kWave) par[i] = gone_par ? 0xFFFFFFFFu : 0u;
             }
         }
+        auto set_fast_range = [&]() {
+            const uint32_t eb = swept << 16, ee = eb + 0x10000u;            // (len < 2^31: swept < 2^15)
+            f_lo = len >= 56u ? (fast_lo > eb ? fast_lo : eb) : 0xFFFFFFFFu;
+            f_hi = len >= 56u ? (len - 40u < ee ? len - 40u : ee) : 0u;
+        };
+        set_fast_range();
         // The cursor enters epoch E (> swept): entries of epoch E-2 and older go out of reach.
         auto sweep_to = [&](uint32_t E) {
             const uint32_t keep_par = (E - 1u) & 1u;
@@ -108,6 +117,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 for (uint32_t i = lane; i < kSlots / 32; i += kWave) par[i] = keep_par ? 0xFFFFFFFFu : 0u;
             }
             swept = E;
+            set_fast_range();
         };
 
         // 8 input bytes at pos; bytes at or beyond len read as 0
@@ -160,9 +170,10 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             // then up to 48 at a time.  Written out straight; the general batch below does the same with schedule arithmetic,
             // end-of-input lanes and epoch cuts, and takes over wherever this loop stops.
             bool found = false;
-            while (c >= fast_lo && n < 58u) {
+            while (n < 58u) {
                 const uint32_t bw = n == 0u ? kFirstBatch : (66u - n < 48u ? 66u - n : 48u);
-                if (!(c + bw + 40u <= len && (c >> 16) == swept && ((c + bw - 1u) >> 16) == (c >> 16))) break;   // (len < 2^31: no wrap)
+                if (c < f_lo) break;
+                if (c + bw > f_hi) break;                                   // (len < 2^31: no wrap)
                 if (DRY) ++work;
                 const bool inb = lane < bw;
                 const uint32_t ck = c + lane;
@@ -246,7 +257,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     // known here): no extension, no epoch change, <= 14 literals, match length in the token, room in the sink.
                     {
                         const uint32_t cur2 = m_pos + m, ex2 = m - 4u + bt, L2 = (m_pos - bt) - ls;
-                        if (ins_h != 0xFFFFFFFFu && !more_bt && (cur2 >> 16) == swept && cur2 + kFirstBatch + 40u <= len &&
+                        if (ins_h != 0xFFFFFFFFu && !more_bt && cur2 + kFirstBatch <= f_hi &&      // (same epoch, 56 readable bytes)
                             (L2 > ex2 ? L2 : ex2) < 15u && s.cap - s.pos >= L2 + 3u) {
                             if (DRY) ++work;
                             cursor = cur2;                                                 // :215
