@@ -179,7 +179,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 const uint32_t ck = c + lane;
                 const uint32_t have = bw > kProbeLanes ? bw : kProbeLanes;   // lanes holding 16 input bytes (c + 40 + bw <= len: readable)
                 uint64_t A0 = 0, A1 = 0;
-                if (n == 0u && pf_c == c) { A0 = pfA0; A1 = pfA1; }
+                if (pf_c == c) { A0 = pfA0; A1 = pfA1; }                  // (only a run's first batch: pf_c is cleared below)
                 else if (lane < have) { A0 = ld8(in + ck); A1 = ld8(in + ck + 8u); }
                 pf_c = 0xFFFFFFFFu;
                 const uint32_t h = hash5(A0);
@@ -244,37 +244,40 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     const uint32_t wpk = __builtin_amdgcn_readlane(pk, W);
                     m_pos = c + W;
                     m_cand = __builtin_amdgcn_readlane(cand, W);
-                    m = wpk & 31u;
-                    more_m = m >= 16u;
-                    bt = (wpk >> 5) & 15u;
-                    more_bt = ((wpk >> 9) & 1u) != 0u;
+                    const uint32_t wm = wpk & 31u, wbt = (wpk >> 5) & 15u;
                     // table.replace(input, cursor - 2) (:218): the 8 bytes at cursor - 2 are the probe bytes of lane W + m - 2, whose
                     // hash is already there (lanes up to `have` hold probe bytes; an extended match is handled at the insert)
-                    const uint32_t qi = W + m - 2u;
-                    if (!more_m && qi < have) ins_h = __builtin_amdgcn_readlane(h, qi);
+                    const uint32_t qi = W + wm - 2u;
                     found = true;
                     // The common sequence in one straight line (everything the general tail below decides with a branch each is
-                    // known here): no extension, no epoch change, <= 14 literals, match length in the token, room in the sink.
-                    {
-                        const uint32_t cur2 = m_pos + m, ex2 = m - 4u + bt, L2 = (m_pos - bt) - ls;
-                        if (ins_h != 0xFFFFFFFFu && !more_bt && cur2 + kFirstBatch <= f_hi &&      // (same epoch, 56 readable bytes)
-                            (L2 > ex2 ? L2 : ex2) < 15u && s.cap - s.pos >= L2 + 3u) {
-                            if (DRY) ++work;
-                            cursor = cur2;                                                 // :215
-                            const uint32_t lj = lane < L2 ? lane : L2;
-                            uint32_t byte = in[ls + (lj ? lj - 1u : 0u)];                // lane j: literal j-1
-                            pfA0 = 0; pfA1 = 0;                                            // the next run's probe bytes, right behind
-                            if (lane < kProbeLanes) { pfA0 = ld8(in + cur2 + lane); pfA1 = ld8(in + cur2 + lane + 8u); }
-                            pf_c = cur2;
-                            insert_hash(cur2 - 2u, ins_h);                                 // :218
-                            const uint32_t off2 = m_pos - m_cand;                          // :208
-                            if (lane == 0u) byte = (L2 << 4) | ex2;                        // write_group, :150-163
-                            if (lane == L2 + 1u) byte = off2;
-                            if (lane == L2 + 2u) byte = off2 >> 8;
-                            if (!DRY && lane < L2 + 3u) s.out[s.pos + lane] = (uint8_t)byte;
-                            s.pos += L2 + 3u;
-                            straight = true;
-                        }
+                    // known here): no extension (m < 16, no more backtrack), the insert's hash at hand, no epoch change and 56
+                    // readable bytes at the new cursor, <= 14 literals, match length in the token, room in the sink — the last
+                    // five as one sign test (every term is negative when its condition fails; all quantities are below 2^31).
+                    const uint32_t cur2 = m_pos + wm, ex2 = wm - 4u + wbt, L2 = (m_pos - wbt) - ls;
+                    const int32_t inrange = (int32_t)(have - 1u - qi) | (int32_t)(f_hi - kFirstBatch - cur2) |
+                                            (int32_t)(14u - (L2 > ex2 ? L2 : ex2)) | (int32_t)(s.cap - s.pos - (L2 + 3u));
+                    if ((wpk & 0x210u) == 0u && inrange >= 0) {
+                        if (DRY) ++work;
+                        cursor = cur2;                                                 // :215
+                        const uint32_t lj = lane < L2 ? lane : L2;
+                        uint32_t byte = in[ls + (lj ? lj - 1u : 0u)];                // lane j: literal j-1
+                        pfA0 = 0; pfA1 = 0;                                            // the next run's probe bytes, right behind
+                        if (lane < kProbeLanes) { pfA0 = ld8(in + cur2 + lane); pfA1 = ld8(in + cur2 + lane + 8u); }
+                        pf_c = cur2;
+                        insert_hash(cur2 - 2u, __builtin_amdgcn_readlane(h, qi));     // :218
+                        const uint32_t off2 = m_pos - m_cand;                          // :208
+                        if (lane == 0u) byte = (L2 << 4) | ex2;                        // write_group, :150-163
+                        if (lane == L2 + 1u) byte = off2;
+                        if (lane == L2 + 2u) byte = off2 >> 8;
+                        if (!DRY && lane < L2 + 3u) s.out[s.pos + lane] = (uint8_t)byte;
+                        s.pos += L2 + 3u;
+                        straight = true;
+                    } else {
+                        m = wm;
+                        more_m = m >= 16u;
+                        bt = wbt;
+                        more_bt = ((wpk >> 9) & 1u) != 0u;
+                        if (!more_m && qi < have) ins_h = __builtin_amdgcn_readlane(h, qi);
                     }
                     break;
                 }
