@@ -251,26 +251,28 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     found = true;
                     // The common sequence in one straight line (everything the general tail below decides with a branch each is
                     // known here): no extension (m < 16, no more backtrack), the insert's hash at hand, no epoch change and 56
-                    // readable bytes at the new cursor, <= 14 literals, match length in the token, room in the sink — the last
-                    // five as one sign test (every term is negative when its condition fails; all quantities are below 2^31).
+                    // readable bytes at the new cursor, <= 57 literals (one LSIC byte at most), match length in the token, room in the sink —
+                    // the last six as one sign test (every term is negative when its condition fails; all quantities are below 2^31).
                     const uint32_t cur2 = m_pos + wm, ex2 = wm - 4u + wbt, L2 = (m_pos - wbt) - ls;
-                    const int32_t inrange = (int32_t)(have - 1u - qi) | (int32_t)(f_hi - kFirstBatch - cur2) |
-                                            (int32_t)(14u - (L2 > ex2 ? L2 : ex2)) | (int32_t)(s.cap - s.pos - (L2 + 3u));
+                    const uint32_t nl2 = L2 >= 15u ? 1u : 0u;                          // literal length beyond the token: one LSIC byte up to 57
+                    const int32_t inrange = (int32_t)(have - 1u - qi) | (int32_t)(f_hi - kFirstBatch - cur2) | (int32_t)(14u - ex2) |
+                                            (int32_t)(57u - L2) | (int32_t)(s.cap - s.pos - (L2 + 3u + nl2));
                     if ((wpk & 0x210u) == 0u && inrange >= 0) {
                         if (DRY) ++work;
                         cursor = cur2;                                                 // :215
-                        const uint32_t lj = lane < L2 ? lane : L2;
-                        uint32_t byte = in[ls + (lj ? lj - 1u : 0u)];                // lane j: literal j-1
+                        const uint32_t lt = lane > nl2 ? lane - nl2 : 0u, lj = lt < L2 ? lt : L2;
+                        uint32_t byte = in[ls + (lj ? lj - 1u : 0u)];                // lane j: literal j - 1 - nl2
                         pfA0 = 0; pfA1 = 0;                                            // the next run's probe bytes, right behind
                         if (lane < kProbeLanes) { pfA0 = ld8(in + cur2 + lane); pfA1 = ld8(in + cur2 + lane + 8u); }
                         pf_c = cur2;
                         insert_hash(cur2 - 2u, __builtin_amdgcn_readlane(h, qi));     // :218
                         const uint32_t off2 = m_pos - m_cand;                          // :208
-                        if (lane == 0u) byte = (L2 << 4) | ex2;                        // write_group, :150-163
-                        if (lane == L2 + 1u) byte = off2;
-                        if (lane == L2 + 2u) byte = off2 >> 8;
-                        if (!DRY && lane < L2 + 3u) s.out[s.pos + lane] = (uint8_t)byte;
-                        s.pos += L2 + 3u;
+                        if (lane == 1u && nl2) byte = L2 - 15u;                        // write_group, :150-163
+                        if (lane == 0u) byte = ((nl2 ? 15u : L2) << 4) | ex2;
+                        if (lane == L2 + nl2 + 1u) byte = off2;
+                        if (lane == L2 + nl2 + 2u) byte = off2 >> 8;
+                        if (!DRY && lane < L2 + nl2 + 3u) s.out[s.pos + lane] = (uint8_t)byte;
+                        s.pos += L2 + nl2 + 3u;
                         straight = true;
                     } else {
                         // An extended match (all 16 compared bytes equal) the same way when it ends within the next 512 bytes: one
