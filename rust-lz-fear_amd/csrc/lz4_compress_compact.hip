@@ -275,53 +275,55 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                         s.pos += L2 + nl2 + 3u;
                         straight = true;
                     } else {
-                        // An extended match (all 16 compared bytes equal) the same way when it ends within the next 512 bytes: one
-                        // compare round of 8 bytes per lane (:203-204), the length's LSIC tail (mod.rs:243-260) in the same store,
-                        // the `cursor - 2` insert deferred to the top of the next iteration like in the general tail.
-                        if ((wpk & 0x210u) == 0x10u && L2 < 15u && m_pos + 16u + 512u + 5u <= len) {
-                            const uint64_t x = ld8(in + m_pos + 16u + lane * 8u) ^ ld8(in + m_cand + 16u + lane * 8u);
-                            const unsigned long long neq = __ballot(x != 0ull);
-                            if (neq) {
-                                const uint32_t fl = (uint32_t)__builtin_ctzll(neq);
-                                const uint32_t xlo = __builtin_amdgcn_readlane((uint32_t)x, fl), xhi = __builtin_amdgcn_readlane((uint32_t)(x >> 32), fl);
-                                const uint32_t me = 16u + fl * 8u + (uint32_t)(__builtin_ctzll(((uint64_t)xhi << 32) | xlo) >> 3);
-                                const uint32_t cur3 = m_pos + me, ex3 = me - 4u + wbt;                    // ex3 in 12 .. 531
-                                const uint32_t nt = ex3 < 15u ? 0u : 1u + (ex3 >= 270u ? 1u : 0u) + (ex3 >= 525u ? 1u : 0u);   // lsic_len
-                                const uint32_t tot3 = L2 + 3u + nt;
-                                if (cur3 + kFirstBatch <= f_hi && s.cap - s.pos >= tot3) {
-                                    if (DRY) ++work;
-                                    cursor = cur3;                                             // :215
-                                    const uint32_t lj = lane < L2 ? lane : L2;
-                                    uint32_t byte = in[ls + (lj ? lj - 1u : 0u)];            // lane j: literal j-1
-                                    pfA0 = 0; pfA1 = 0;
-                                    if (lane < kProbeLanes) { pfA0 = ld8(in + cur3 + lane); pfA1 = ld8(in + cur3 + lane + 8u); }
-                                    pf_c = cur3;
-                                    if (lane == 16u) pfQ = ld8(in + cur3 - 2u);               // :218, inserted before the next probes
-                                    pend_q = cur3 - 2u;
-                                    const uint32_t off3 = m_pos - m_cand;                      // :208
-                                    if (lane > L2 + 2u) byte = 0xFFu;                          // LSIC tail: 0xFF ..., then the rest
-                                    if (lane + 1u == tot3 && nt) byte = ex3 - 15u - 255u * (nt - 1u);
-                                    if (lane == 0u) byte = (L2 << 4) | (ex3 < 15u ? ex3 : 15u);
-                                    if (lane == L2 + 1u) byte = off3;
-                                    if (lane == L2 + 2u) byte = off3 >> 8;
-                                    if (!DRY && lane < tot3) s.out[s.pos + lane] = (uint8_t)byte;
-                                    s.pos += tot3;
-                                    straight = true;
-                                }
-                            }
-                        }
-                        if (!straight) {
-                            m = wm;
-                            more_m = m >= 16u;
-                            bt = wbt;
-                            more_bt = ((wpk >> 9) & 1u) != 0u;
-                            if (!more_m && qi < have) ins_h = __builtin_amdgcn_readlane(h, qi);
-                        }
+                        m = wm;
+                        more_m = m >= 16u;
+                        bt = wbt;
+                        more_bt = ((wpk >> 9) & 1u) != 0u;
+                        if (!more_m && qi < have) ins_h = __builtin_amdgcn_readlane(h, qi);
                     }
                     break;
                 }
             }
             if (straight) continue;
+            // An extended match of the fast search (all 16 compared bytes equal, m == 16 so far) that ends within the next 512
+            // bytes, with a short literal run, also goes in a straight line: one compare round of 8 bytes per lane (:203-204),
+            // the length's LSIC tail (mod.rs:243-260) in the same store, the `cursor - 2` insert deferred to the top of the next
+            // iteration like in the general tail.  (Kept out of the search loop: inside it, it costs the common path scalar moves.)
+            if (found && more_m && !more_bt && m == 16u && m_pos + 16u + 512u + 5u <= len) {
+                const uint32_t L3 = (m_pos - bt) - ls;
+                if (L3 < 15u) {
+                    const uint64_t x = ld8(in + m_pos + 16u + lane * 8u) ^ ld8(in + m_cand + 16u + lane * 8u);
+                    const unsigned long long neq = __ballot(x != 0ull);
+                    if (neq) {
+                        const uint32_t fl = (uint32_t)__builtin_ctzll(neq);
+                        const uint32_t xlo = __builtin_amdgcn_readlane((uint32_t)x, fl), xhi = __builtin_amdgcn_readlane((uint32_t)(x >> 32), fl);
+                        const uint32_t me = 16u + fl * 8u + (uint32_t)(__builtin_ctzll(((uint64_t)xhi << 32) | xlo) >> 3);
+                        const uint32_t cur3 = m_pos + me, ex3 = me - 4u + bt;                          // ex3 in 12 .. 531
+                        const uint32_t nt = ex3 < 15u ? 0u : 1u + (ex3 >= 270u ? 1u : 0u) + (ex3 >= 525u ? 1u : 0u);   // lsic_len
+                        const uint32_t tot3 = L3 + 3u + nt;
+                        if (cur3 + kFirstBatch <= f_hi && s.cap - s.pos >= tot3) {
+                            if (DRY) ++work;
+                            cursor = cur3;                                                 // :215
+                            const uint32_t lj = lane < L3 ? lane : L3;
+                            uint32_t byte = in[ls + (lj ? lj - 1u : 0u)];                // lane j: literal j-1
+                            pfA0 = 0; pfA1 = 0;
+                            if (lane < kProbeLanes) { pfA0 = ld8(in + cur3 + lane); pfA1 = ld8(in + cur3 + lane + 8u); }
+                            pf_c = cur3;
+                            if (lane == 16u) pfQ = ld8(in + cur3 - 2u);                   // :218, inserted before the next probes
+                            pend_q = cur3 - 2u;
+                            const uint32_t off3 = m_pos - m_cand;                          // :208
+                            if (lane > L3 + 2u) byte = 0xFFu;                              // LSIC tail: 0xFF ..., then the rest
+                            if (lane + 1u == tot3 && nt) byte = ex3 - 15u - 255u * (nt - 1u);
+                            if (lane == 0u) byte = (L3 << 4) | (ex3 < 15u ? ex3 : 15u);
+                            if (lane == L3 + 1u) byte = off3;
+                            if (lane == L3 + 2u) byte = off3 >> 8;
+                            if (!DRY && lane < tot3) s.out[s.pos + lane] = (uint8_t)byte;
+                            s.pos += tot3;
+                            continue;
+                        }
+                    }
+                }
+            }
             // ================= search: speculative batches of the :177-232 loop
             if (!found) for (;;) {
                 if (DRY) ++work;
