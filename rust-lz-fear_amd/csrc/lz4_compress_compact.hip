@@ -170,10 +170,10 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             // then up to 48 at a time.  Written out straight; the general batch below does the same with schedule arithmetic,
             // end-of-input lanes and epoch cuts, and takes over wherever this loop stops.
             bool found = false;
-            while (n < 58u) {
-                const uint32_t bw = n == 0u ? kFirstBatch : (66u - n < 48u ? 66u - n : 48u);
-                if (c < f_lo) break;
-                if (c + bw > f_hi) break;                                   // (len < 2^31: no wrap)
+            // (a lambda so that the first batch — 16 probes, bw a compile-time constant, n == 0 — is compiled on its own)
+            auto fast_batch = [&](const uint32_t bw) __attribute__((always_inline)) -> bool {    // true: the fast search is over
+                if (c < f_lo) return true;
+                if (c + bw > f_hi) return true;                                   // (len < 2^31: no wrap)
                 if (DRY) ++work;
                 const bool inb = lane < bw;
                 const uint32_t ck = c + lane;
@@ -281,9 +281,12 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                         more_bt = ((wpk >> 9) & 1u) != 0u;
                         if (!more_m && qi < have) ins_h = __builtin_amdgcn_readlane(h, qi);
                     }
-                    break;
+                    return true;
                 }
-            }
+                return false;
+            };
+            if (!fast_batch(kFirstBatch))
+                while (n < 58u) { if (fast_batch(66u - n < 48u ? 66u - n : 48u)) break; }
             if (straight) continue;
             // An extended match of the fast search (all 16 compared bytes equal, m == 16 so far) that ends within the next 512
             // bytes, with a short literal run, also goes in a straight line: one compare round of 8 bytes per lane (:203-204),
