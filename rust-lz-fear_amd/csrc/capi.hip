@@ -39,7 +39,7 @@ int ensure_device() {
 // Kernel variant used by lzf_decompress_batch.  Tuning / A-B knob only (every variant implements the same
 // contract): LZF_DECOMPRESS_KERNEL = wave (first generation, one sequence at a time) or one of the names in
 // LZF_DECOMPRESS_VARIANTS (kernels.h).  Unknown names select the default.
-enum { kVariantAuto = -1, kVariantWave = 0, kVariantFirstBatched = 1, kVariantFirstWindowed = 100, kVariantFirstPaired = 200 };
+enum { kVariantAuto = -1, kVariantWave = 0, kVariantFirstBatched = 1, kVariantFirstWindowed = 100, kVariantFirstPaired = 200, kVariantFirstWalk = 300 };
 // Variant by name; "auto" (the default) = the producer/consumer pair kernel, with 48-byte regions while every block's
 // workgroup is resident at once (lowest latency per block: the copy stage is the critical path, the parse rides along)
 // and 24-byte regions beyond that (smaller LDS footprint, more blocks in flight); batches of more than eight times that
@@ -59,6 +59,10 @@ static int variant_by_name(const char* e) {
 #define LZF_NAMEP(NAME, RG, S_, T) if (!strcmp(e, #NAME)) return id; ++id;
     LZF_PAIRED_VARIANTS(LZF_NAMEP)
 #undef LZF_NAMEP
+    id = kVariantFirstWalk;
+#define LZF_NAMEK(NAME, RG, S_, T) if (!strcmp(e, #NAME)) return id; ++id;
+    LZF_WALK_VARIANTS(LZF_NAMEK)
+#undef LZF_NAMEK
     return kVariantAuto;                       // unknown names select the default
 }
 uint32_t cu_count() {
@@ -171,6 +175,12 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
         if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<R, S_, T, ST>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, cperm);
         LZF_DECOMPRESS_VARIANTS(LZF_LAUNCH)
 #undef LZF_LAUNCH
+    } else if (variant >= kVariantFirstWalk) {
+        int id = kVariantFirstWalk;
+#define LZF_LAUNCHK(NAME, RG, S_, T) \
+        if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_walk_kernel<RG, S_, T>), dim3(n_jobs), dim3(128), 0, st, d_jobs, d_results, n_jobs, cperm);
+        LZF_WALK_VARIANTS(LZF_LAUNCHK)
+#undef LZF_LAUNCHK
     } else if (variant >= kVariantFirstPaired) {
         int id = kVariantFirstPaired;
 #define LZF_LAUNCHP(NAME, RG, S_, T) \

@@ -41,6 +41,18 @@ __global__ void lzf_decompress_paired_kernel(const lzf_decompress_job* __restric
 #define LZF_EXTP(NAME, RG, S_, T) extern template __global__ void lzf_decompress_paired_kernel<RG, S_, T>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*);
 LZF_PAIRED_VARIANTS(LZF_EXTP)
 #undef LZF_EXTP
+// Region-walk parser + the same copy stage (lz4_decompress_walk.hip): X(name, ring bytes, region bytes, token-list entries).
+template <int RING, int S, int TOKCAP>
+__global__ void lzf_decompress_walk_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
+                                           const uint32_t* __restrict__ perm);
+#define LZF_WALK_VARIANTS(X) \
+    X(walk48, 4096, 48, 640)  \
+    X(walk64, 4096, 64, 768)  \
+    X(walk96, 4096, 96, 1152) \
+    X(walk128, 4096, 128, 1536)
+#define LZF_EXTK(NAME, RG, S_, T) extern template __global__ void lzf_decompress_walk_kernel<RG, S_, T>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*);
+LZF_WALK_VARIANTS(LZF_EXTK)
+#undef LZF_EXTK
 template <int KIND>
 __global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
                                          lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t skip_compact,
