@@ -39,7 +39,7 @@ int ensure_device() {
 // Kernel variant used by lzf_decompress_batch.  Tuning / A-B knob only (every variant implements the same
 // contract): LZF_DECOMPRESS_KERNEL = wave (first generation, one sequence at a time) or one of the names in
 // LZF_DECOMPRESS_VARIANTS (kernels.h).  Unknown names select the default.
-enum { kVariantAuto = -1, kVariantWave = 0, kVariantFirstBatched = 1, kVariantFirstWindowed = 100, kVariantFirstPaired = 200, kVariantFirstWalk = 300 };
+enum { kVariantAuto = -1, kVariantWave = 0, kVariantFirstBatched = 1, kVariantFirstWindowed = 100, kVariantFirstPaired = 200, kVariantFirstWalk = 300, kVariantFirstV4 = 400 };
 // Variant by name; "auto" (the default) = the producer/consumer pair kernel, with 48-byte regions while every block's
 // workgroup is resident at once (lowest latency per block: the copy stage is the critical path, the parse rides along)
 // and 24-byte regions beyond that (smaller LDS footprint, more blocks in flight); batches of more than eight times that
@@ -63,6 +63,10 @@ static int variant_by_name(const char* e) {
 #define LZF_NAMEK(NAME, RG, S_, T) if (!strcmp(e, #NAME)) return id; ++id;
     LZF_WALK_VARIANTS(LZF_NAMEK)
 #undef LZF_NAMEK
+    id = kVariantFirstV4;
+#define LZF_NAME4(NAME, W_, S_, T, P) if (!strcmp(e, #NAME)) return id; ++id;
+    LZF_V4_VARIANTS(LZF_NAME4)
+#undef LZF_NAME4
     return kVariantAuto;                       // unknown names select the default
 }
 uint32_t cu_count() {
@@ -175,6 +179,12 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
         if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<R, S_, T, ST>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, cperm);
         LZF_DECOMPRESS_VARIANTS(LZF_LAUNCH)
 #undef LZF_LAUNCH
+    } else if (variant >= kVariantFirstV4) {
+        int id = kVariantFirstV4;
+#define LZF_LAUNCH4(NAME, W_, S_, T, P) \
+        if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_v4_kernel<W_, S_, T, P>), dim3(n_jobs), dim3(128), 0, st, d_jobs, d_results, n_jobs, cperm);
+        LZF_V4_VARIANTS(LZF_LAUNCH4)
+#undef LZF_LAUNCH4
     } else if (variant >= kVariantFirstWalk) {
         int id = kVariantFirstWalk;
 #define LZF_LAUNCHK(NAME, RG, S_, T) \

@@ -53,6 +53,21 @@ __global__ void lzf_decompress_walk_kernel(const lzf_decompress_job* __restrict_
 #define LZF_EXTK(NAME, RG, S_, T) extern template __global__ void lzf_decompress_walk_kernel<RG, S_, T>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*);
 LZF_WALK_VARIANTS(LZF_EXTK)
 #undef LZF_EXTK
+// Pair kernel with the second copy stage (lz4_decompress_v4.hip): X(name, window bytes, region bytes, token-list entries, parser)
+// parser 0 = tabulating (nxt[] / ex[]), 1 = region walk.
+template <int W, int S, int TOKCAP, int PARSER>
+__global__ void lzf_decompress_v4_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
+                                         const uint32_t* __restrict__ perm);
+#define LZF_V4_VARIANTS(X) \
+    X(v4t24, 4096, 24, 384, 0)   \
+    X(v4t48, 4096, 48, 640, 0)   \
+    X(v4t24w6, 6144, 24, 384, 0) \
+    X(v4t24w8, 8192, 24, 384, 0) \
+    X(v4w64, 4096, 64, 768, 1)   \
+    X(v4w96, 4096, 96, 1152, 1)
+#define LZF_EXT4(NAME, W_, S_, T, P) extern template __global__ void lzf_decompress_v4_kernel<W_, S_, T, P>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*);
+LZF_V4_VARIANTS(LZF_EXT4)
+#undef LZF_EXT4
 template <int KIND>
 __global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
                                          lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t skip_compact,

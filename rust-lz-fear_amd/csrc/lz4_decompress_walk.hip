@@ -135,184 +135,7 @@ __global__ __launch_bounds__(128) void lzf_decompress_walk_kernel(
                             }
                         }
                     }
-                    // byte of the input at absolute position q >= cstart
-                    auto rdb = [&](uint32_t q) -> uint32_t {
-                        const uint32_t r = q - cstart;
-                        if (r < kCB) return lds_ld8(cbuf_a + r);
-                        return (uint32_t)in[q];
-                    };
-                    // One token at p (p < len), general form: position of the next token; false on UnexpectedEnd.
-                    // decompress.rs:61-71 without the copies.
-                    auto token_next = [&](uint32_t p, uint32_t& next) -> bool {
-                        const uint32_t tok = rdb(p);
-                        uint32_t q = p + 1u;
-                        uint32_t L = tok >> 4;
-                        if (L == 15u) {
-                            uint32_t b;
-                            do {
-                                if (q >= len) return false;
-                                b = rdb(q); ++q;
-                                L += b; if (L > kMaxPosB) L = kMaxPosB;
-                            } while (b == 255u);
-                        }
-                        if (len - q < L) return false;                    // :67 read_exact
-                        q += L;
-                        if (len - q < 2u) { next = len; return true; }    // :70 read_u16 fails: last literals
-                        q += 2u;
-                        if ((tok & 15u) == 15u) {
-                            for (;;) {
-                                if (q >= len) return false;
-                                const uint32_t b = rdb(q); ++q;
-                                if (b != 255u) break;
-                            }
-                        }
-                        next = q;
-                        return true;
-                    };
-                    // plain hops: the next token starts below fe (chunk-relative): inside the staged bytes and clear of the input's end
-                    const uint32_t room = len - cstart;
-                    const uint32_t fe = room > 24u ? (room - 24u < kCB ? room - 24u : kCB) : 0u;
-                    const uint32_t rb0 = lane * (uint32_t)S;          // region start, chunk-relative
-                    uint32_t cutpos_w = 0;                            // position of token #TOKCAP when the chunk has more than the list holds
-                    uint64_t marks[NM];
-#pragma unroll
-                    for (uint32_t i = 0; i < NM; ++i) marks[i] = 0;
-                    auto mark_bit = [&](uint32_t r) -> uint64_t { return 1ull << ((r - rb0) & 63u); };
-                    // MODE 0: mark the visited token positions (pass 0); 1: stop on a marked position; 2: record token entries at toks[k++]
-                    // Walks from p (absolute) up to, not including, the first token at or beyond `end`; n counts the tokens.
-                    auto walk = [&](uint32_t p, const uint32_t end, bool go, uint32_t& n, uint32_t& k, bool& err, bool& merged, auto MODE) -> uint32_t {
-                        constexpr int mode = decltype(MODE)::value;
-                        const uint32_t end_r = end - cstart;
-                        const uint32_t stop = go ? (end_r < fe ? end_r : fe) : 0u;
-                        uint32_t r = p - cstart;
-                        for (;;) {
-                            uint32_t mxp = 0, rprev = r;
-                            bool act = r < stop && !merged;
-                            while (__any(act)) {
-                                const uint64_t w = lds_ld64(cbuf_a + (act ? r : 0u) - 1u);
-                                const uint32_t lo = (uint32_t)w;
-                                const uint32_t e0 = lo & 255u;
-                                const bool bad = act && mxp != 0u && e0 == 255u;     // the previous token's match length goes on: not plain
-                                if (mode == 2) {
-                                    if (act && mxp != 0u && !bad && k - 1u < (uint32_t)TOKCAP) {
-                                        const uint32_t mc = 15u + e0 < 254u ? 15u + e0 : 255u;
-                                        lds_st8(toks_a + 4u * (k - 1u) + 3u, mc);
-                                    }
-                                }
-                                if (bad) { n -= 1u; k -= 1u; r = rprev; act = false; }
-                                if (act && r >= stop) act = false;                   // done (or handed to the general routine below)
-                                if (mode == 1) {
-                                    if (act) {
-                                        const uint32_t bi = r - rb0;
-                                        uint64_t mw = marks[0];
-#pragma unroll
-                                        for (uint32_t i = 1; i < NM; ++i) if ((bi >> 6) == i) mw = marks[i];
-                                        if ((mw >> (bi & 63u)) & 1ull) { merged = true; act = false; }
-                                    }
-                                }
-                                if (act) {
-                                    const uint32_t L0 = (lo >> 12) & 15u, M0 = (lo >> 8) & 15u, b1 = (lo >> 16) & 255u;
-                                    const uint32_t isx = L0 == 15u ? 1u : 0u;
-                                    const uint32_t Lt = L0 + (isx ? b1 : 0u);
-                                    const uint32_t mx = M0 == 15u ? 1u : 0u;
-                                    const uint32_t rn = r + 3u + isx + Lt + mx;
-                                    const bool plain = !(isx && b1 == 255u) && rn < fe;
-                                    if (plain) {
-                                        ++n;
-                                        if (mode == 0) {
-                                            const uint32_t bi = r - rb0;
-#pragma unroll
-                                            for (uint32_t i = 0; i < NM; ++i) if ((bi >> 6) == i) marks[i] |= 1ull << (bi & 63u);
-                                        }
-                                        if (mode == 2) {
-                                            if (k < (uint32_t)TOKCAP) toks[k] = r | ((Lt < 255u ? Lt : 255u) << 16) | (M0 << 24);
-                                            else if (k == (uint32_t)TOKCAP) cutpos_w = cstart + r;
-                                            ++k;
-                                        }
-                                        rprev = r; r = rn; mxp = mx;
-                                    } else {
-                                        act = false;                                  // parked: the general routine takes this token
-                                    }
-                                }
-                            }
-                            // the general routine serves parked lanes and lanes near the end of the input
-                            const uint32_t pa = cstart + r;
-                            const bool slow = go && !merged && r < end_r && pa < len;
-                            if (!__any(slow)) break;
-                            if (slow) {
-                                uint32_t nx;
-                                if (!token_next(pa, nx)) { err = true; r = len - cstart; }
-                                else {
-                                    ++n;
-                                    if (mode == 0) {
-                                        const uint32_t bi = r - rb0;
-#pragma unroll
-                                        for (uint32_t i = 0; i < NM; ++i) if ((bi >> 6) == i) marks[i] |= 1ull << (bi & 63u);
-                                    }
-                                    if (mode == 2) {
-                                        if (k < (uint32_t)TOKCAP) toks[k] = r | 0xFFFF0000u;      // escape: the copy stage decodes this token in full
-                                        else if (k == (uint32_t)TOKCAP) cutpos_w = pa;
-                                        ++k;
-                                    }
-                                    r = nx - cstart;
-                                }
-                            }
-                        }
-                        return cstart + r;
-                    };
-                    (void)mark_bit;
-                    using M0 = std::integral_constant<int, 0>; using M1 = std::integral_constant<int, 1>; using M2 = std::integral_constant<int, 2>;
-                    const uint32_t rbeg = cstart + rb0, rend = rbeg + (uint32_t)S;
-                    // ---- pass 0: from the region starts
-                    uint32_t kdummy = 0, n0 = 0;
-                    bool e0f = false, mdummy = false;
-                    const bool in_input = rbeg < len;
-                    const uint32_t x0 = walk(in_input ? rbeg : len, rend, in_input, n0, kdummy, e0f, mdummy, M0{});
-                    uint32_t X = x0, N = n0, walked = rbeg;
-                    bool lerr = e0f;
-                    // ---- passes: start[i] = max(exit[0..i-1]) until nothing changes
-                    for (uint32_t pass = 0; pass < 80u; ++pass) {
-                        const uint32_t entry = wave_prev(wave_scan_max(X), cstart);      // (lane 0: the chunk's true first token = its region start)
-                        const bool redo = entry != walked;
-                        if (!__any(redo)) break;
-                        if (redo) walked = entry;
-                        const bool inreg = entry < rend && entry < len;
-                        uint32_t n1 = 0; bool e1 = false, mg = false;
-                        const uint32_t x1 = walk(inreg ? entry : len, rend, redo && inreg, n1, kdummy, e1, mg, M1{});
-                        if (redo) {
-                            if (!inreg) { X = entry; N = 0; lerr = false; }
-                            else if (mg) {
-                                // joined the pass-0 chain at x1: its exit, and its tokens from x1 on
-                                const uint32_t bi = x1 - rbeg;
-                                uint32_t below = 0;
-#pragma unroll
-                                for (uint32_t i = 0; i < NM; ++i) {
-                                    const uint64_t mk = (bi >> 6) > i ? ~0ull : (bi >> 6) == i ? ((1ull << (bi & 63u)) - 1ull) : 0ull;
-                                    below += (uint32_t)__popcll(marks[i] & mk);
-                                }
-                                X = x0; N = n1 + (n0 - below); lerr = e0f;
-                            } else { X = x1; N = n1; lerr = e1; }
-                        }
-                    }
-                    // ---- token ranks in stream order, then the record walk
-                    const uint32_t incl_n = wave_scan_add(N);
-                    const uint32_t rank0 = incl_n - N;
-                    const uint32_t T = __builtin_amdgcn_readlane(incl_n, 63);
-                    const bool cut = T > (uint32_t)TOKCAP;
-                    const uint32_t Tc = cut ? (uint32_t)TOKCAP : T;
-                    {
-                        uint32_t k = rank0, n2 = 0; bool e2 = false, m2 = false;
-                        const bool inreg = walked < rend && walked < len;
-                        (void)walk(inreg ? walked : len, rend, inreg, n2, k, e2, m2, M2{});
-                    }
-                    uint32_t cend;        // where the next chunk starts
-                    int cerr = LZF_OK;    // UnexpectedEnd right after the listed tokens
-                    if (cut) {
-                        cend = __builtin_amdgcn_readlane(cutpos_w, first_lane(__ballot(rank0 <= (uint32_t)TOKCAP && rank0 + N > (uint32_t)TOKCAP)) & 63u);
-                    } else {
-                        cend = __builtin_amdgcn_readlane(wave_scan_max(X), 63);
-                        if (__ballot(lerr)) cerr = LZF_UNEXPECTED_END;
-                    }
+#include "lz4_decompress_walk_phase.inc"
                     if (lane == 0u) { ctl_T[bsel] = Tc; ctl_cstart[bsel] = cstart; ctl_err[bsel] = cerr; }
                     cend_next = cend;
                 }
