@@ -39,7 +39,7 @@ int ensure_device() {
 // Kernel variant used by lzf_decompress_batch.  Tuning / A-B knob only (every variant implements the same
 // contract): LZF_DECOMPRESS_KERNEL = wave (first generation, one sequence at a time) or one of the names in
 // LZF_DECOMPRESS_VARIANTS (kernels.h).  Unknown names select the default.
-enum { kVariantAuto = -1, kVariantWave = 0, kVariantFirstBatched = 1, kVariantFirstWindowed = 100, kVariantFirstPaired = 200, kVariantFirstWalk = 300, kVariantFirstV4 = 400 };
+enum { kVariantAuto = -1, kVariantWave = 0, kVariantFirstBatched = 1, kVariantFirstWindowed = 100, kVariantFirstPaired = 200, kVariantFirstWalk = 300, kVariantFirstV4 = 400, kVariantFirstV5 = 500 };
 // Variant by name; "auto" (the default) = the producer/consumer pair kernel, with 48-byte regions while every block's
 // workgroup is resident at once (lowest latency per block: the copy stage is the critical path, the parse rides along)
 // and 24-byte regions beyond that (smaller LDS footprint, more blocks in flight); batches of more than eight times that
@@ -67,6 +67,10 @@ static int variant_by_name(const char* e) {
 #define LZF_NAME4(NAME, W_, S_, T, P) if (!strcmp(e, #NAME)) return id; ++id;
     LZF_V4_VARIANTS(LZF_NAME4)
 #undef LZF_NAME4
+    id = kVariantFirstV5;
+#define LZF_NAME5(NAME, W_, S_) if (!strcmp(e, #NAME)) return id; ++id;
+    LZF_V5_VARIANTS(LZF_NAME5)
+#undef LZF_NAME5
     return kVariantAuto;                       // unknown names select the default
 }
 uint32_t cu_count() {
@@ -179,6 +183,27 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
         if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<R, S_, T, ST>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, cperm);
         LZF_DECOMPRESS_VARIANTS(LZF_LAUNCH)
 #undef LZF_LAUNCH
+    } else if (variant >= kVariantFirstV5) {
+        // the chunk token lists live in stream-ordered global scratch: 2 lists per workgroup of a launch
+        uint32_t words = 0;
+        { int id = kVariantFirstV5;
+#define LZF_WORDS5(NAME, W_, S_) if (variant == id++) words = 2u * LZF_V5_LISTWORDS(S_);
+          LZF_V5_VARIANTS(LZF_WORDS5)
+#undef LZF_WORDS5
+        }
+        const uint32_t kSlice = 16384;           // jobs per launch: bounds the scratch area
+        const uint32_t slots = n_jobs < kSlice ? n_jobs : kSlice;
+        uint32_t* scratch = nullptr;
+        HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), (size_t)slots * words * sizeof(uint32_t), st));
+        for (uint32_t base = 0; base < n_jobs; base += kSlice) {
+            const uint32_t cnt = n_jobs - base < kSlice ? n_jobs - base : kSlice;
+            int id = kVariantFirstV5;
+#define LZF_LAUNCH5(NAME, W_, S_) \
+            if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_v5_kernel<W_, S_>), dim3(cnt), dim3(128), 0, st, d_jobs, d_results, n_jobs, cperm, scratch, base);
+            LZF_V5_VARIANTS(LZF_LAUNCH5)
+#undef LZF_LAUNCH5
+        }
+        HIP_TRY(hipFreeAsync(scratch, st));
     } else if (variant >= kVariantFirstV4) {
         int id = kVariantFirstV4;
 #define LZF_LAUNCH4(NAME, W_, S_, T, P) \

@@ -68,6 +68,21 @@ __global__ void lzf_decompress_v4_kernel(const lzf_decompress_job* __restrict__ 
 #define LZF_EXT4(NAME, W_, S_, T, P) extern template __global__ void lzf_decompress_v4_kernel<W_, S_, T, P>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*);
 LZF_V4_VARIANTS(LZF_EXT4)
 #undef LZF_EXT4
+// Fifth generation (lz4_decompress_v5.hip): X(name, window bytes, region bytes).  The token list of a chunk lives in global
+// scratch: 2 x LZF_V5_LISTWORDS(region) 32-bit words per workgroup of the launch.
+template <int W, int S>
+__global__ void lzf_decompress_v5_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
+                                         const uint32_t* __restrict__ perm, uint32_t* __restrict__ scratch, uint32_t base);
+#define LZF_V5_TOKCAP(S_) ((64 * (S_)) / 3 + 1)
+#define LZF_V5_LISTWORDS(S_) ((uint32_t)((LZF_V5_TOKCAP(S_) + 64 + 63) / 64 * 64))
+#define LZF_V5_VARIANTS(X) \
+    X(v5s512, 4096, 512)   \
+    X(v5s512w6, 6144, 512) \
+    X(v5s256, 4096, 256)   \
+    X(v5s1024, 4096, 1024)
+#define LZF_EXT5(NAME, W_, S_) extern template __global__ void lzf_decompress_v5_kernel<W_, S_>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*, uint32_t*, uint32_t);
+LZF_V5_VARIANTS(LZF_EXT5)
+#undef LZF_EXT5
 template <int KIND>
 __global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
                                          lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t skip_compact,
