@@ -8,7 +8,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.environ.get("LZF_LIB_PATH") or os.path.join(PKG_DIR, "liblzfear_hip.so")   # override: debug builds only
 
-HIP_SOURCES = ["capi.hip", "lz4_decompress.hip", "lz4_decompress_batched.hip", "lz4_decompress_windowed.hip", "lz4_decompress_paired.hip", "lz4_decompress_walk.hip", "lz4_decompress_v4.hip", "lz4_decompress_v5.hip", "lz4_compress.hip", "lz4_compress_compact.hip", "aux_kernels.hip"]
+HIP_SOURCES = ["capi.hip", "lz4_decompress.hip", "lz4_decompress_batched.hip", "lz4_decompress_windowed.hip", "lz4_decompress_paired.hip", "lz4_decompress_walk.hip", "lz4_decompress_v4.hip", "lz4_decompress_v5.hip", "lz4_decompress_v6.hip", "lz4_compress.hip", "lz4_compress_compact.hip", "aux_kernels.hip"]
 CXX_SOURCES = ["frame.cpp"]
 DEPS = HIP_SOURCES + CXX_SOURCES + ["kernels.h", "lzf_device.h", "lz4_decompress_batch_phase.inc", "lz4_decompress_parse_phase.inc", "lz4_decompress_walk_phase.inc", "lz4_decompress_copy2.inc", "lz4_decompress_copy3.inc", "lz4_decompress_gwalk_phase.inc", "lzf_copy_helpers.h", "lzf_parse_helpers.h", "lzf_compress_common.h", os.path.join(ROOT, "include", "lzfear_hip.h"),
                                      os.path.join(ROOT, "include", "lzfear_frame.h")]

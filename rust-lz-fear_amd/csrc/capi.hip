@@ -39,7 +39,7 @@ int ensure_device() {
 // Kernel variant used by lzf_decompress_batch.  Tuning / A-B knob only (every variant implements the same
 // contract): LZF_DECOMPRESS_KERNEL = wave (first generation, one sequence at a time) or one of the names in
 // LZF_DECOMPRESS_VARIANTS (kernels.h).  Unknown names select the default.
-enum { kVariantAuto = -1, kVariantWave = 0, kVariantFirstBatched = 1, kVariantFirstWindowed = 100, kVariantFirstPaired = 200, kVariantFirstWalk = 300, kVariantFirstV4 = 400, kVariantFirstV5 = 500 };
+enum { kVariantAuto = -1, kVariantWave = 0, kVariantFirstBatched = 1, kVariantFirstWindowed = 100, kVariantFirstPaired = 200, kVariantFirstWalk = 300, kVariantFirstV4 = 400, kVariantFirstV5 = 500, kVariantFirstV6 = 600 };
 // Variant by name; "auto" (the default) = the producer/consumer pair kernel, with 48-byte regions while every block's
 // workgroup is resident at once (lowest latency per block: the copy stage is the critical path, the parse rides along)
 // and 24-byte regions beyond that (smaller LDS footprint, more blocks in flight); batches of more than eight times that
@@ -68,9 +68,13 @@ static int variant_by_name(const char* e) {
     LZF_V4_VARIANTS(LZF_NAME4)
 #undef LZF_NAME4
     id = kVariantFirstV5;
-#define LZF_NAME5(NAME, W_, S_) if (!strcmp(e, #NAME)) return id; ++id;
+#define LZF_NAME5(NAME, W_, S_, ST) if (!strcmp(e, #NAME)) return id; ++id;
     LZF_V5_VARIANTS(LZF_NAME5)
 #undef LZF_NAME5
+    id = kVariantFirstV6;
+#define LZF_NAME6(NAME, W_, S_, ST) if (!strcmp(e, #NAME)) return id; ++id;
+    LZF_V6_VARIANTS(LZF_NAME6)
+#undef LZF_NAME6
     return kVariantAuto;                       // unknown names select the default
 }
 uint32_t cu_count() {
@@ -183,11 +187,79 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
         if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_batched_kernel<R, S_, T, ST>), dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, cperm);
         LZF_DECOMPRESS_VARIANTS(LZF_LAUNCH)
 #undef LZF_LAUNCH
+    } else if (variant >= kVariantFirstV6) {
+        // Parse and copy as two launches per slice of the batch.  The parse of slice s + 1 runs on a side stream while the caller's
+        // stream copies slice s (the parse is bound by dependent-load latency, the copy by instruction issue: they overlap well).
+        // The token lists and chunk tables of a slice live in stream-ordered scratch sized from the jobs' compressed sizes, which
+        // only the device knows: one small device -> host copy (and one wait on the side stream) per call.
+        static const uint32_t parse_dyn_lds = [] { const char* e = getenv("LZF_V6_PARSE_WAVES"); const long v = e ? atol(e) : 0; return v > 0 ? (uint32_t)(160u * 1024u / (uint32_t)v - 8192u) : 0u; }();
+        static const uint32_t kParts = [] { const char* e = getenv("LZF_V6_PARTS"); const long v = e ? atol(e) : 0; return v > 0 ? (uint32_t)v : 1u; }();
+        static thread_local hipStream_t side = nullptr;
+        if (!side) {
+            HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            // keep the stream-ordered pool's memory between calls (the default gives it back at every synchronisation point, and
+            // mapping gigabytes of scratch again costs far more than the kernels)
+            int dev = 0; hipMemPool_t pool = nullptr;
+            if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+                uint64_t keep = ~0ull;
+                (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            }
+            (void)hipGetLastError();
+        }
+        uint32_t chunk_bytes = 0;
+        { int id = kVariantFirstV6;
+#define LZF_CHUNK6(NAME, W_, S_, ST) if (variant == id++) chunk_bytes = 64u * S_;
+          LZF_V6_VARIANTS(LZF_CHUNK6)
+#undef LZF_CHUNK6
+        }
+        // the parts interleave the launch order (part s = launch indices s, s + K, ...): every part gets the same mix of long and short jobs
+        const uint32_t n_slices = n_jobs >= 4096u * kParts ? kParts : 1u;
+        hipEvent_t ev_in = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(ev_in, st));                      // the jobs (and the launch order) are ready on the caller's stream
+        HIP_TRY(hipStreamWaitEvent(side, ev_in, 0));
+        uint64_t* offs = nullptr;                                 // per slice: cnt + 1 token offsets, cnt + 1 table offsets
+        HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&offs), sizeof(uint64_t) * 2u * ((size_t)n_jobs + 2u * n_slices), side));
+        std::vector<uint64_t*> tok_off(n_slices), tab_off(n_slices);
+        std::vector<uint64_t> totals(2u * n_slices, 0);
+        { uint64_t* p = offs;
+          for (uint32_t s = 0; s < n_slices; ++s) {
+              const uint32_t base = s, cnt = (n_jobs - s + n_slices - 1u) / n_slices;
+              tok_off[s] = p; p += cnt + 1u; tab_off[s] = p; p += cnt + 1u;
+              hipLaunchKernelGGL(lzf::lzf_v6_plan_kernel, dim3(1), dim3(1024), 0, side, d_jobs, n_jobs, base, n_slices, cnt, cperm, chunk_bytes, tok_off[s], tab_off[s]);
+              HIP_TRY(hipMemcpyAsync(&totals[2u * s], tok_off[s] + cnt, sizeof(uint64_t), hipMemcpyDeviceToHost, side));
+              HIP_TRY(hipMemcpyAsync(&totals[2u * s + 1u], tab_off[s] + cnt, sizeof(uint64_t), hipMemcpyDeviceToHost, side));
+          } }
+        HIP_TRY(hipStreamSynchronize(side));
+        // (all slices' scratch up front: an allocation that re-used memory freed on the other stream would serialise the two)
+        std::vector<uint32_t*> scratch(n_slices, nullptr);
+        for (uint32_t s = 0; s < n_slices; ++s)
+            HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch[s]), sizeof(uint32_t) * (size_t)(totals[2u * s] + totals[2u * s + 1u] + 64u), side));
+        for (uint32_t s = 0; s < n_slices; ++s) {
+            const uint32_t base = s, cnt = (n_jobs - s + n_slices - 1u) / n_slices;
+            uint32_t* toks_all = scratch[s]; uint32_t* tabs_all = scratch[s] + totals[2u * s];
+            hipEvent_t ev_parsed = nullptr;
+            HIP_TRY(hipEventCreateWithFlags(&ev_parsed, hipEventDisableTiming));
+            int id = kVariantFirstV6;
+#define LZF_LAUNCH6(NAME, W_, S_, ST) \
+            if (variant == id++) { \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_v6_parse_kernel<S_, ST>), dim3(cnt), dim3(64), parse_dyn_lds, side, d_jobs, n_jobs, base, n_slices, cperm, tok_off[s], tab_off[s], toks_all, tabs_all); \
+                HIP_TRY(hipEventRecord(ev_parsed, side)); \
+                HIP_TRY(hipStreamWaitEvent(st, ev_parsed, 0)); \
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_v6_copy_kernel<W_>), dim3(cnt), dim3(64), 0, st, d_jobs, d_results, n_jobs, base, n_slices, cperm, tok_off[s], tab_off[s], (const uint32_t*)toks_all, (const uint32_t*)tabs_all); \
+            }
+            LZF_V6_VARIANTS(LZF_LAUNCH6)
+#undef LZF_LAUNCH6
+            HIP_TRY(hipEventDestroy(ev_parsed));
+        }
+        for (uint32_t s = 0; s < n_slices; ++s) HIP_TRY(hipFreeAsync(scratch[s], st));
+        HIP_TRY(hipFreeAsync(offs, st));
+        HIP_TRY(hipEventDestroy(ev_in));
     } else if (variant >= kVariantFirstV5) {
         // the chunk token lists live in stream-ordered global scratch: 2 lists per workgroup of a launch
         uint32_t words = 0;
         { int id = kVariantFirstV5;
-#define LZF_WORDS5(NAME, W_, S_) if (variant == id++) words = 2u * LZF_V5_LISTWORDS(S_);
+#define LZF_WORDS5(NAME, W_, S_, ST) if (variant == id++) words = 2u * LZF_V5_LISTWORDS(S_);
           LZF_V5_VARIANTS(LZF_WORDS5)
 #undef LZF_WORDS5
         }
@@ -198,8 +270,8 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
         for (uint32_t base = 0; base < n_jobs; base += kSlice) {
             const uint32_t cnt = n_jobs - base < kSlice ? n_jobs - base : kSlice;
             int id = kVariantFirstV5;
-#define LZF_LAUNCH5(NAME, W_, S_) \
-            if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_v5_kernel<W_, S_>), dim3(cnt), dim3(128), 0, st, d_jobs, d_results, n_jobs, cperm, scratch, base);
+#define LZF_LAUNCH5(NAME, W_, S_, ST) \
+            if (variant == id++) hipLaunchKernelGGL(HIP_KERNEL_NAME(lzf::lzf_decompress_v5_kernel<W_, S_, ST>), dim3(cnt), dim3(128), 0, st, d_jobs, d_results, n_jobs, cperm, scratch, base);
             LZF_V5_VARIANTS(LZF_LAUNCH5)
 #undef LZF_LAUNCH5
         }

@@ -70,19 +70,40 @@ LZF_V4_VARIANTS(LZF_EXT4)
 #undef LZF_EXT4
 // Fifth generation (lz4_decompress_v5.hip): X(name, window bytes, region bytes).  The token list of a chunk lives in global
 // scratch: 2 x LZF_V5_LISTWORDS(region) 32-bit words per workgroup of the launch.
-template <int W, int S>
+template <int W, int S, bool STAGED>
 __global__ void lzf_decompress_v5_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
                                          const uint32_t* __restrict__ perm, uint32_t* __restrict__ scratch, uint32_t base);
 #define LZF_V5_TOKCAP(S_) ((64 * (S_)) / 3 + 1)
 #define LZF_V5_LISTWORDS(S_) ((uint32_t)((LZF_V5_TOKCAP(S_) + 64 + 63) / 64 * 64))
 #define LZF_V5_VARIANTS(X) \
-    X(v5s512, 4096, 512)   \
-    X(v5s512w6, 6144, 512) \
-    X(v5s256, 4096, 256)   \
-    X(v5s1024, 4096, 1024)
-#define LZF_EXT5(NAME, W_, S_) extern template __global__ void lzf_decompress_v5_kernel<W_, S_>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*, uint32_t*, uint32_t);
+    X(v5s512, 4096, 512, false)  \
+    X(v5l256, 4096, 256, true)   \
+    X(v5l128, 4096, 128, true)   \
+    X(v5l384, 4096, 384, true)
+#define LZF_EXT5(NAME, W_, S_, ST) extern template __global__ void lzf_decompress_v5_kernel<W_, S_, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*, uint32_t*, uint32_t);
 LZF_V5_VARIANTS(LZF_EXT5)
 #undef LZF_EXT5
+// Sixth generation (lz4_decompress_v6.hip): parse and copy as two launches; X(name, window bytes, region bytes).
+__global__ void lzf_v6_plan_kernel(const lzf_decompress_job* __restrict__ jobs, uint32_t n_jobs, uint32_t base, uint32_t stride, uint32_t cnt, const uint32_t* __restrict__ perm,
+                                   uint32_t chunk_bytes, uint64_t* __restrict__ tok_off, uint64_t* __restrict__ tab_off);
+template <int S, bool STAGED>
+__global__ void lzf_v6_parse_kernel(const lzf_decompress_job* __restrict__ jobs, uint32_t n_jobs, uint32_t base, uint32_t stride, const uint32_t* __restrict__ perm,
+                                    const uint64_t* __restrict__ tok_off, const uint64_t* __restrict__ tab_off, uint32_t* __restrict__ toks_all, uint32_t* __restrict__ tabs_all);
+template <int W>
+__global__ void lzf_v6_copy_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t base, uint32_t stride,
+                                   const uint32_t* __restrict__ perm, const uint64_t* __restrict__ tok_off, const uint64_t* __restrict__ tab_off,
+                                   const uint32_t* __restrict__ toks_all, const uint32_t* __restrict__ tabs_all);
+#define LZF_V6_VARIANTS(X) \
+    X(v6s512, 4096, 512, false)  \
+    X(v6l256, 4096, 256, true)   \
+    X(v6l128, 4096, 128, true)   \
+    X(v6l384, 4096, 384, true)   \
+    X(v6l256w6, 6144, 256, true)
+#define LZF_EXT6(NAME, W_, S_, ST) \
+    extern template __global__ void lzf_v6_parse_kernel<S_, ST>(const lzf_decompress_job*, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint64_t*, const uint64_t*, uint32_t*, uint32_t*); \
+    extern template __global__ void lzf_v6_copy_kernel<W_>(const lzf_decompress_job*, lzf_job_result*, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint64_t*, const uint64_t*, const uint32_t*, const uint32_t*);
+LZF_V6_VARIANTS(LZF_EXT6)
+#undef LZF_EXT6
 template <int KIND>
 __global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
                                          lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t skip_compact,

@@ -20,18 +20,20 @@
 
 namespace lzf {
 
-template <int W, int S>
+template <int W, int S, bool STAGED>
 __global__ __launch_bounds__(128) void lzf_decompress_v5_kernel(
     const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
     const uint32_t* __restrict__ perm, uint32_t* __restrict__ scratch, uint32_t base) {
-    constexpr int SPAN = W / 4;                        // output bytes one batch may produce
+    constexpr int SPAN = 3 * W / 8;                    // output bytes one batch may produce
     constexpr int HKEEP = W / 2;                       // history a slide keeps
     static_assert(HKEEP + SPAN + 96 <= W && W % 1024 == 0, "a batch fits behind the kept history");
     constexpr uint32_t kChunk = 64u * S;               // compressed bytes whose tokens one parse covers
     static_assert(kChunk <= 65536 && S % 128 == 0, "token positions are 16-bit chunk offsets; mark rows are cleared 16 bytes at a time");
     constexpr int TOKCAP = LZF_V5_TOKCAP(S);           // a token is at least 3 bytes
-    __shared__ __attribute__((aligned(16))) uint8_t win[W + 32 + 512 + 16];        // window + per-lane scratch words
+    __shared__ __attribute__((aligned(16))) uint8_t win[W + 32 + 512 + 16 + 1024 + 32]; // window + per-lane scratch words + the batch's 1 KB of compressed input
     __shared__ __attribute__((aligned(16))) uint8_t marks[kChunk / 8u];             // parser: visited positions of pass 0, one row per lane
+    constexpr uint32_t kCB = kChunk + 64u;             // staged bytes: the chunk + room for token bodies
+    __shared__ __attribute__((aligned(16))) uint8_t cbufs[STAGED ? 16u + kCB + 16u : 16u];   // parser: the chunk's bytes (staged variants)
     __shared__ uint32_t ctl_T[2], ctl_cstart[2];
     __shared__ int ctl_err[2], ctl_valid[2], ctl_stop;
 
@@ -69,7 +71,40 @@ __global__ __launch_bounds__(128) void lzf_decompress_v5_kernel(
                 const bool valid = cstart < len && *(volatile int*)&ctl_stop == 0;
                 uint32_t cend_next = cstart;
                 if (valid) {
+                    uint32_t Tc_, cend_; int cerr_;
+                    if constexpr (STAGED) {
+                        // ---- stage in[cstart, cstart + kCB) in LDS (zeros beyond the input): every hop is then one LDS read
+                        const uint32_t cbuf_a = lds_addr(cbufs) + 16u;
+                        {
+                            uint8_t* const cbuf = cbufs + 16u;
+                            const uint32_t avail = len - cstart < kCB ? len - cstart : kCB;
+                            cgu8* g = in + cstart;
+#pragma unroll 1
+                            for (uint32_t b4 = 0; b4 < kCB; b4 += 4u * 1024u) {
+                                u32x4 v[4];
+#pragma unroll
+                                for (uint32_t k = 0; k < 4u; ++k) {
+                                    const uint32_t i = b4 + k * 1024u + lane * 16u;
+                                    v[k] = u32x4{0, 0, 0, 0};
+                                    if (i + 16u <= avail) v[k] = ld16(g + i);
+                                    else if (i < avail) { for (uint32_t t = 0; i + t < avail; ++t) v[k][(t >> 2) & 3u] |= (uint32_t)g[i + t] << ((t & 3u) * 8u); }
+                                }
+#pragma unroll
+                                for (uint32_t k = 0; k < 4u; ++k) {
+                                    const uint32_t i = b4 + k * 1024u + lane * 16u;
+                                    if (i < kCB) *reinterpret_cast<u32x4*>(&cbuf[i]) = v[k];
+                                }
+                            }
+                        }
+#define LZF_GWALK_STAGED 1
 #include "lz4_decompress_gwalk_phase.inc"
+#undef LZF_GWALK_STAGED
+                        Tc_ = Tc; cend_ = cend; cerr_ = cerr;
+                    } else {
+#include "lz4_decompress_gwalk_phase.inc"
+                        Tc_ = Tc; cend_ = cend; cerr_ = cerr;
+                    }
+                    const uint32_t Tc = Tc_, cend = cend_; const int cerr = cerr_;
                     if (lane == 0u) { ctl_T[bsel] = Tc; ctl_cstart[bsel] = cstart; ctl_err[bsel] = cerr; }
                     cend_next = cend;
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the list's stores have left this wave (L2 holds them)
@@ -108,6 +143,7 @@ __global__ __launch_bounds__(128) void lzf_decompress_v5_kernel(
             };
             o = (uint32_t)job.out_existing_len;
             uint32_t safe = o;   // out[0, safe) is visible to this wave's global loads
+            long long dbg_cycles = 0, dbg_t0 = 0; int dbg_sec = 0; (void)dbg_cycles; (void)dbg_t0; (void)dbg_sec;
             hlo = o > (uint32_t)HKEEP ? o - (uint32_t)HKEEP : 0u;
             wlo = AL(hlo);
             if (o > hlo) win_fill(hlo, o);       // Vec content on entry = history
@@ -146,7 +182,7 @@ __global__ __launch_bounds__(128) void lzf_decompress_v5_kernel(
     }
 }
 
-#define LZF_INST5(NAME, W_, S_) template __global__ void lzf_decompress_v5_kernel<W_, S_>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*, uint32_t*, uint32_t);
+#define LZF_INST5(NAME, W_, S_, ST) template __global__ void lzf_decompress_v5_kernel<W_, S_, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*, uint32_t*, uint32_t);
 LZF_V5_VARIANTS(LZF_INST5)
 #undef LZF_INST5
 

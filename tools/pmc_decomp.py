@@ -32,3 +32,6 @@ for it in range(reps):
     device.decompress_batch(d_dj, d_res2, m); torch.cuda.synchronize()
     dt = time.time() - t
     print(f"jobs {m} raw {raw} time {dt*1e3:.2f} ms  {raw/dt/2**30:.1f} GiB/s", flush=True)
+if os.environ.get("LZF_PRINT_RESERVED"):
+    r2 = device.results_to_host(d_res2, m)
+    print(f"reserved: mean {r2['reserved'].mean():.1f} kcycles/job, sum {int(r2['reserved'].sum())} ; status ok {int((r2['status'] == 0).sum())}/{m}", flush=True)
