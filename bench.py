@@ -1,35 +1,43 @@
 #!/usr/bin/env python3
 """bench.py — GiB/s of the LZ4 raw-block hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W [--workload silesia|config4]
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-Workload (config.workload, BASELINE.json configs[1]): the Silesia stand-in `silesia_mix`
-(211 938 580 B, rust-lz-fear_amd/synth.py) cut into 4 MiB independent blocks, tiled `--copies`
-times per GPU so that one launch has enough independent blocks to occupy 256 CUs; a "step" is
-one decompress pass over every block this rank owns (kernel for compressed blocks + the
-device copy the frame layer does for stored blocks).  Inputs are resident in HBM before the
-timed region.  Blocks shard across ranks with no data-path collective ("weak" scaling: per-GPU
-work fixed).  The compress pass over the same blocks (configs[2]) is timed too and reported
-under "compress".
+--workload silesia (default; BASELINE.json configs[1], compress of the same blocks = configs[2] under "compress"):
+  the Silesia stand-in `silesia_mix` (211 938 580 B, rust-lz-fear_amd/synth.py) cut into 4 MiB independent blocks and tiled
+  `--copies` times per GPU so that one launch has enough independent blocks to occupy 256 CUs.  `--distinct` copies are
+  generated with their own seeds ("tiled with distinct seeds"); copy k beyond them is distinct copy k % distinct
+  rotated by a copy-specific number of bytes (the 4 MiB cuts fall elsewhere, so the blocks differ in content and cost) and
+  XOR-ed with a copy-specific byte.  A "step" is one decompress pass over every block this rank owns: the kernel over the
+  compressed blocks + the device copy the frame layer does for stored blocks (framed/decompress.rs:250).  Inputs are resident
+  in HBM before the timed region.  Blocks shard across ranks with no data-path collective ("weak": per-GPU work fixed).
+
+--workload config4 (BASELINE.json configs[3]): a `log_text` stream of 2048 x 4 MiB blocks (8 GiB; --blocks scales it), framed
+  independent-blocks mode, sharded by contiguous block ranges across the ranks.  A step = device compress of the rank's
+  blocks -> size table + payload all-gather over torch.distributed (RCCL) -> the frame assembled in HBM on every rank, all
+  inside the timed region ("strong": total work fixed).  The frame is checked against the oracle's frame on a prefix.
 """
 import argparse
-import concurrent.futures
+import ctypes as C
 import json
+import multiprocessing
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import rust_lz_fear_amd  # noqa: E402,F401
-from rust_lz_fear_amd import device, ffi, synth  # noqa: E402
+from rust_lz_fear_amd import synth  # noqa: E402
 
 BS = 4 << 20
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+METRIC = "GiB/s compress + decompress, 4 MiB independent blocks, 1/2/4/8 MI355X"
 
 
 def log(*a):
@@ -37,16 +45,118 @@ def log(*a):
         print(*a, file=sys.stderr, flush=True)
 
 
-def timed_launches(fn, steps):
-    """Run fn() `steps` times; HIP events on the launch stream bracket each call."""
-    evs = []
-    for _ in range(steps):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record()
-        fn()
-        b.record()
-        evs.append((a, b))
-    return evs
+# --------------------------------------------------------------------------------------- corpus (host, before CUDA is touched)
+def _gen_copy(args):
+    k, path = args
+    np.save(path, synth.silesia_mix(copy=k))
+    return path
+
+
+def make_distinct_copies(distinct):
+    """`distinct` copies of silesia_mix with their own seeds, generated in parallel (numpy, one process each)."""
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    tmp = tempfile.mkdtemp(prefix="lzfbench_", dir=shm)
+    jobs = [(k, os.path.join(tmp, f"c{k}.npy")) for k in range(distinct)]
+    nproc = max(1, min(distinct, (os.cpu_count() or 2) // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))))
+    if nproc > 1:
+        with multiprocessing.get_context("fork").Pool(nproc) as pool:
+            paths = pool.map(_gen_copy, jobs)
+    else:
+        paths = [_gen_copy(j) for j in jobs]
+    arrs = [np.load(p) for p in paths]
+    for p in paths:
+        os.unlink(p)
+    os.rmdir(tmp)
+    return arrs
+
+
+# --------------------------------------------------------------------------------------- CPU baseline (native threads)
+def build_cpubench():
+    """oracle/lzf_cpu_bench.c + lzf_oracle.c compiled HERE for this host (-march=native), into a temporary directory."""
+    d = tempfile.mkdtemp(prefix="lzfcpu_")
+    so = os.path.join(d, "liblzf_cpubench.so")
+    src = [os.path.join(ROOT, "oracle", f) for f in ("lzf_cpu_bench.c", "lzf_oracle.c")]
+    subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=gnu11", "-pthread", "-shared", "-o", so] + src + ["-ldl"])
+    L = C.CDLL(so)
+    L.lzfo_bench_run.restype = C.c_int
+    L.lzfo_bench_run.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.lzfo_bench_liblz4_version.restype = C.c_char_p
+    return L
+
+
+def cpu_model():
+    model, gov = "unknown", "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    try:
+        gov = open("/sys/devices/system/cpu/cpu0/cpufreq/scaling_governor").read().strip()
+    except OSError:
+        gov = "n/a (no cpufreq in this guest)"
+    return model, gov
+
+
+def cpu_baseline(raw_blocks, comp_blocks, budget_s):
+    """The CPU restatement of lz-fear (oracle/, kind "port": the Rust reference cannot be built here) and liblz4 (the C
+    implementation the reference compares itself with, README.md:11,18), timed with native threads on this host:
+    single thread and all hardware threads, median of 5 passes each, over the same 4 MiB blocks the GPU decodes."""
+    L = build_cpubench()
+    cores = os.cpu_count() or 1
+    n = len(raw_blocks)
+    nbytes = sum(len(b) for b in raw_blocks)
+    reps = 5
+
+    def arrs(blocks, mult):
+        ptrs = (C.c_void_p * (n * mult))(*([b.ctypes.data for b in blocks] * mult))
+        lens = (C.c_uint64 * (n * mult))(*([len(b) for b in blocks] * mult))
+        return ptrs, lens
+
+    def run(what, threads, mult):
+        rp, rl = arrs(raw_blocks, mult)
+        cp, cl = arrs(comp_blocks, mult)
+        secs = (C.c_double * reps)()
+        inp, inl = (rp, rl) if what in (0, 2) else (cp, cl)
+        rc = L.lzfo_bench_run(what, inp, inl, rl, n * mult, threads, reps, secs)
+        if rc != 0:
+            return None
+        return round(nbytes * mult / sorted(secs)[reps // 2] / 2**30, 3)
+
+    # enough block-jobs per pass that every thread gets several (the same blocks again: read-only inputs)
+    mult_all = max(1, (4 * cores + n - 1) // n)
+    t0 = time.time()
+    out = {"single_thread": {"decompress": run(1, 1, 1), "compress": run(0, 1, 1)},
+           "all_cores": {"decompress": run(1, cores, mult_all), "compress": run(0, cores, mult_all)}}
+    ver = L.lzfo_bench_liblz4_version()
+    if ver and time.time() - t0 < budget_s:
+        out["liblz4"] = {"version": ver.decode(), "single_thread": {"decompress": run(3, 1, 1), "compress": run(2, 1, 1)},
+                         "all_cores": {"decompress": run(3, cores, mult_all), "compress": run(2, cores, mult_all)}}
+    else:
+        out["liblz4"] = None
+    model, gov = cpu_model()
+    out.update({"value": out["all_cores"]["decompress"], "unit": "GiB/s (decompress, uncompressed bytes; all hardware threads)",
+                "cores": cores, "kind": "port", "cpu_model": model, "governor": gov, "reps": reps,
+                "compress_value": out["all_cores"]["compress"],
+                "sample": f"the {n} compressible 4 MiB blocks of one corpus copy ({nbytes / 2**20:.0f} MiB), {mult_all} x per all-core pass; "
+                          f"native pthreads (oracle/lzf_cpu_bench.c, gcc -O3 -march=native), median of {reps} passes; "
+                          "oracle/lzf_oracle.c = lz-fear restated in C; liblz4 = LZ4_compress_fast_continue on a fresh stream / LZ4_decompress_safe"})
+    return out
+
+
+# --------------------------------------------------------------------------------------- HBM traffic (PMC passes under profiles/)
+def traffic_for(kernel_name, which, n_jobs):
+    """FETCH_SIZE (x2: gfx950 correction) + WRITE_SIZE of the launched kernel, from the separate --pmc passes committed as
+    profiles/r02_hbm_traffic.json (tools/refresh_profiles.sh), scaled by job count; None when the profile is of another kernel."""
+    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    if not os.path.exists(path):
+        return None
+    tj = json.load(open(path)).get(which)
+    if not tj or tj.get("kernel") != kernel_name:
+        return None
+    return (2 * tj["FETCH_SIZE_KB"] + tj["WRITE_SIZE_KB"]) * 1024.0 * n_jobs / tj["jobs"]
 
 
 def decompress_kernel_name(n_jobs):
@@ -59,14 +169,30 @@ def decompress_kernel_name(n_jobs):
     return "lzf_decompress_paired_kernel<4096,24,384>" if n_jobs <= 16384 else "lzf_decompress_batched_kernel<4096,16,256,staged>"
 
 
+def timed_launches(torch, fn, steps):
+    """Run fn() `steps` times; HIP events on the launch stream bracket each call."""
+    evs = []
+    for _ in range(steps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        fn()
+        b.record()
+        evs.append((a, b))
+    return evs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--copies", type=int, default=240, help="tiled copies of silesia_mix per GPU (51 blocks each)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU-baseline leg (rank 0, N=1)")
+    ap.add_argument("--workload", choices=["silesia", "config4"], default="silesia")
+    ap.add_argument("--copies", type=int, default=240, help="silesia: tiled copies of silesia_mix per GPU (51 blocks each)")
+    ap.add_argument("--distinct", type=int, default=12, help="silesia: copies generated with their own seeds (the rest are rotated + XOR-ed)")
+    ap.add_argument("--blocks", type=int, default=2048, help="config4: 4 MiB blocks of the whole stream (2048 = 8 GiB)")
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU-baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     args = ap.parse_args()
 
@@ -74,6 +200,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    t0 = time.time()
+    bases = None
+    if args.workload == "silesia":
+        bases = make_distinct_copies(max(1, min(args.distinct, args.copies)))
+        log(f"[bench] {len(bases)} distinct-seed copies of silesia_mix generated ({time.time() - t0:.1f}s)")
+
+    import torch
+    from rust_lz_fear_amd import device, ffi
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -84,24 +219,40 @@ def main():
         dist = dist_mod
     assert ffi.device_count() >= 1
 
-    # ------------------------------------------------------------------ inputs (synthetic)
+    if args.workload == "config4":
+        line = run_config4(args, torch, device, ffi, dist, rank, world, dev)
+    else:
+        line = run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+# ======================================================================================= configs[1] / configs[2]
+def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
     t0 = time.time()
-    base = torch.from_numpy(synth.silesia_mix()).to(dev)
-    total = base.numel()
+    total = bases[0].size
     nb1 = (total + BS - 1) // BS                      # 51 blocks per copy, the last one short
     copies = args.copies
     nblk = nb1 * copies
-    # every copy gets its own slab of nb1 * BS bytes (block-aligned); copy k > 0 = base ^ c_k so
-    # that no two copies hold the same bytes (global copy index differs per rank)
+    d_bases = [torch.from_numpy(b).to(dev) for b in bases]
+    nd = len(d_bases)
     src = torch.zeros(nblk * BS, dtype=torch.uint8, device=dev)
     lens = np.full(nblk, BS, dtype=np.uint64)
     for k in range(copies):
-        g = rank * copies + k
-        c = (g * 37 + (g >> 3)) & 0xFF if g else 0
+        g = rank * copies + k                                         # global copy index: no two copies anywhere hold the same bytes
+        b = d_bases[g % nd]
+        gen = g // nd                                                 # 0: the distinct copy itself
         dst = src[k * nb1 * BS:k * nb1 * BS + total]
-        torch.bitwise_xor(base, c, out=dst) if c else dst.copy_(base)
+        if gen == 0:
+            dst.copy_(b)
+        else:
+            shift = (gen * 1000003 + (g % nd) * 65537) % total        # rotate: the 4 MiB cuts land elsewhere
+            c = (gen * 37 + (gen >> 3) + 1) & 0xFF
+            torch.bitwise_xor(torch.roll(b, shift), c, out=dst)
         lens[k * nb1 + nb1 - 1] = total - (nb1 - 1) * BS
-    del base
+    del d_bases
     torch.cuda.synchronize()
     log(f"[bench] rank {rank}: {nblk} blocks, {src.numel() / 2**30:.2f} GiB source in HBM ({time.time() - t0:.1f}s)")
 
@@ -126,7 +277,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     tc0 = time.perf_counter()
-    c_evs = timed_launches(compress_step, c_steps)
+    c_evs = timed_launches(torch, compress_step, c_steps)
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -143,27 +294,19 @@ def main():
     # stored blocks (incompressible, framed/compress.rs:250-255): the frame carries the raw bytes
     stored_idx = np.nonzero(full)[0]
     comp2d, src2d = comp.view(nblk, BS), src.view(nblk, BS)
+    t_idx = None
     if len(stored_idx):
         t_idx = torch.from_numpy(stored_idx.astype(np.int64)).to(dev)
         comp2d[t_idx] = src2d[t_idx]
-        # device-side move of the stored blocks during decompression (lzf_copy_ranges, on a second stream so that it
-        # overlaps the decompress kernel)
+        # device-side move of the stored blocks during decompression (lzf_copy_ranges, on a second stream beside the kernel)
         sidx = stored_idx.astype(np.uint64)
         d_sp = torch.from_numpy((np.uint64(comp.data_ptr()) + sidx * np.uint64(BS)).view(np.int64)).to(dev)
-        d_dp_base = sidx * np.uint64(BS)
         d_sl = torch.from_numpy(lens[stored_idx].astype(np.uint64).view(np.int64)).to(dev)
         side = torch.cuda.Stream(device=dev)
-    else:
-        t_idx = None
 
     # ------------------------------------------------------------------ decompress (configs[1])
     dec = torch.zeros(nblk * BS, dtype=torch.uint8, device=dev)
-    dec2d = dec.view(nblk, BS)
     kidx = np.nonzero(ok)[0]
-    if os.environ.get("LZF_BENCH_SORT", "0") == "1":
-        # analysis knob: longest-compressed-first job array built here.  Not needed any more: lzf_decompress_batch and
-        # lzf_compress_batch order large batches on the device themselves (LZF_DECOMPRESS_ORDER / LZF_COMPRESS_ORDER).
-        kidx = kidx[np.argsort(-clen[kidx].astype(np.int64), kind="stable")]
     nk = len(kidx)
     dj = np.zeros(nk, dtype=device.DJOB)
     dj["input"] = np.uint64(comp.data_ptr()) + kidx.astype(np.uint64) * np.uint64(BS)
@@ -178,17 +321,17 @@ def main():
         device.decompress_batch(d_dj, d_dres, nk)
 
     if t_idx is not None:
-        d_dp = torch.from_numpy((np.uint64(dec.data_ptr()) + d_dp_base).view(np.int64)).to(dev)
+        d_dp = torch.from_numpy((np.uint64(dec.data_ptr()) + sidx * np.uint64(BS)).view(np.int64)).to(dev)
+    evs = []
 
     def decompress_step():
         if t_idx is not None:                                          # framed/decompress.rs:250, next to the kernel
             side.wait_stream(torch.cuda.current_stream())
             device.copy_ranges(d_sp, d_dp, d_sl, len(stored_idx), BS, stream=side)
-        evs.extend(timed_launches(decompress_kernel, 1))
+        evs.extend(timed_launches(torch, decompress_kernel, 1))
         if t_idx is not None:
             torch.cuda.current_stream().wait_stream(side)
 
-    evs = []
     for _ in range(args.warmup):
         decompress_step()
     evs.clear()
@@ -213,109 +356,201 @@ def main():
         assert torch.equal(dec, src), "decoded bytes differ from the source"   # round trip at full size
 
     t = torch.tensor([elapsed, tc], dtype=torch.float64, device=dev)
-    tot = torch.tensor([float(lens.sum())], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(lens.sum()), float(lens[kidx].sum())], dtype=torch.float64, device=dev)
     if dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
     elapsed_max, tc_max = float(t[0]), float(t[1])
-    total_bytes = float(tot[0])
+    total_bytes, kernel_bytes = float(tot[0]), float(tot[1])
 
     d_bytes = float(lens[kidx].sum() + clen[kidx].sum())               # C + N of the kernel's jobs
-    # HBM traffic from the PMC passes committed under profiles/ (FETCH_SIZE doubled per the gfx950
-    # correction + WRITE_SIZE), scaled from the profiled launch to this launch by job count
-    d_traffic = c_traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if os.path.exists(tpath):
-        tj = json.load(open(tpath))
-        d_traffic = (2 * tj["decompress"]["FETCH_SIZE_KB"] + tj["decompress"]["WRITE_SIZE_KB"]) * 1024.0 * nk / tj["decompress"]["jobs"]
-        c_traffic = (2 * tj["compress"]["FETCH_SIZE_KB"] + tj["compress"]["WRITE_SIZE_KB"]) * 1024.0 * nblk / tj["compress"]["jobs"]
+    kname = decompress_kernel_name(nk)
+    d_traffic = traffic_for(kname, "decompress", nk)
+    c_traffic = traffic_for("lzf_compress_compact_kernel<false>", "compress", nblk)
     d_achieved = d_bytes / (d_kernel_ms * 1e-3) / 1e9
     c_achieved = c_bytes / (c_kernel_ms * 1e-3) / 1e9
 
-    # ------------------------------------------------------------------ CPU baseline (rank 0, N = 1)
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
-        cpu = cpu_baseline(comp2d, clen, lens, kidx, args.cpu_seconds)
+    # ------------------------------------------------------------------ CPU baseline + host-buffer end to end (rank 0, N = 1)
+    cpu = e2e = None
+    if rank == 0 and world == 1:
+        first = [i for i in range(nb1) if ok[i]]
+        raw_blocks = [bases[0][i * BS:i * BS + int(lens[i])] for i in first]
+        if not args.no_cpu:
+            comp_blocks = [comp2d[i, : int(clen[i])].cpu().numpy() for i in first]
+            cpu = cpu_baseline(raw_blocks, comp_blocks, args.cpu_seconds)
+        if not args.no_e2e:
+            del dec
+            e2e = end_to_end(bases, ffi)
 
-    if rank == 0:
-        value = total_bytes * args.steps / elapsed_max / 2**30
-        line = {
-            "metric": "GiB/s compress + decompress, 4 MiB independent blocks, 1/2/4/8 MI355X",
-            "value": round(value, 3), "unit": "GiB/s (uncompressed bytes decompressed per second)",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "silesia_mix (Silesia stand-in, 211938580 B) x %d copies per GPU, 4 MiB independent "
-                                   "blocks, decompress_raw of every block (configs[1]); lz4 ratio %.3f" %
-                                   (copies, float(lens.sum()) / float(clen.sum() + lens[stored_idx].sum())),
-                       "blocks_per_gpu": int(nblk), "stored_blocks_per_gpu": int(len(stored_idx)),
-                       "block_size": BS, "parallelism": f"block-sharded x{world}, no collective"},
-            "roofline": {"bound": "hbm", "kernel": decompress_kernel_name(nk),
-                         "achieved": round(d_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(d_achieved / HBM_PEAK_GBS, 5), "traffic": d_traffic,
-                         "algorithmic_bytes_per_launch": d_bytes, "kernel_ms": round(d_kernel_ms, 4)},
-            "compress": {"value": round(total_bytes * c_steps / tc_max / 2**30, 3), "unit": "GiB/s (uncompressed bytes compressed per second)",
-                         "steps": c_steps, "ms_per_step": round(tc_max / c_steps * 1e3, 3),
-                         "roofline": {"bound": "hbm", "kernel": "lzf_compress_compact_kernel",
-                                      "achieved": round(c_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "frac": round(c_achieved / HBM_PEAK_GBS, 5), "traffic": c_traffic,
-                                      "algorithmic_bytes_per_launch": c_bytes, "kernel_ms": round(c_kernel_ms, 3)}},
-            "cpu_baseline": cpu,
-        }
-        print(json.dumps(line), flush=True)
+    if rank != 0:
+        return None
+    value = total_bytes * args.steps / elapsed_max / 2**30
+    return {
+        "metric": METRIC,
+        "value": round(value, 3), "unit": "GiB/s (uncompressed bytes decompressed per second)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "silesia_mix (Silesia stand-in, 211938580 B) x %d copies per GPU (%d with their own seeds, the rest "
+                               "rotated + XOR-ed), 4 MiB independent blocks, decompress_raw of every block (configs[1]); lz4 ratio %.3f" %
+                               (copies, len(bases), float(lens.sum()) / float(clen.sum() + lens[stored_idx].sum())),
+                   "blocks_per_gpu": int(nblk), "stored_blocks_per_gpu": int(len(stored_idx)),
+                   "block_size": BS, "parallelism": f"block-sharded x{world}, no collective"},
+        # the kernel alone over the compressed blocks (the stored ones are a device memcpy beside it)
+        "kernel_only": {"value": round(kernel_bytes / world / (d_kernel_ms * 1e-3) / 2**30 * world, 3), "unit": "GiB/s over the compressed blocks only",
+                        "blocks_per_gpu": int(nk)},
+        "roofline": {"bound": "hbm", "kernel": kname,
+                     "achieved": round(d_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(d_achieved / HBM_PEAK_GBS, 5), "traffic": d_traffic,
+                     "algorithmic_bytes_per_launch": d_bytes, "kernel_ms": round(d_kernel_ms, 4),
+                     "north_star_frac": round(float(lens[kidx].sum()) / (d_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+        "compress": {"value": round(total_bytes * c_steps / tc_max / 2**30, 3), "unit": "GiB/s (uncompressed bytes compressed per second)",
+                     "steps": c_steps, "ms_per_step": round(tc_max / c_steps * 1e3, 3),
+                     "roofline": {"bound": "hbm", "kernel": "lzf_compress_compact_kernel<false>",
+                                  "achieved": round(c_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(c_achieved / HBM_PEAK_GBS, 5), "traffic": c_traffic,
+                                  "algorithmic_bytes_per_launch": c_bytes, "kernel_ms": round(c_kernel_ms, 3)}},
+        "cpu_baseline": cpu,
+        "end_to_end": e2e,
+    }
+
+
+def end_to_end(bases, ffi):
+    """The C ABI from HOST buffers (lzfear_frame.h): F frames of 16 MiB per call, 4 MiB independent blocks, default settings.
+    PCIe in and out, frame scan / assembly and checksums included — never the bench `value`."""
+    from rust_lz_fear_amd import framed
+    L = ffi.lib()
+    F, fsz = 64, 16 << 20
+    mix = bases[0]
+    datas = [mix[(i * fsz) % (mix.size - fsz):][:fsz].tobytes() for i in range(F)]
+    n = len(datas)
+    total = sum(len(d) for d in datas)
+    s = framed.CompressionSettings()._struct(None)
+    caps = [L.lzf_frame_compress_bound(C.byref(s), len(d)) for d in datas]
+    outs = [C.create_string_buffer(c) for c in caps]
+    ins = (C.c_char_p * n)(*datas)
+    lens = (C.c_size_t * n)(*[len(d) for d in datas])
+    outp = (C.c_void_p * n)(*[C.cast(o, C.c_void_p) for o in outs])
+    capa = (C.c_size_t * n)(*caps)
+    olen = (C.c_size_t * n)()
+    st = (C.c_int * n)()
+    res = {"frames": n, "frame_bytes": fsz, "settings": "default (4 MiB independent blocks, content checksum)", "buffers": "pageable host memory"}
+    tcs = []
+    for _ in range(3):
+        t = time.perf_counter()
+        rc = L.lzf_frame_compress_many(C.byref(s), n, ins, lens, outp, capa, olen, st)
+        tcs.append(time.perf_counter() - t)
+        assert rc == 0 and not any(st)
+    frames = [outs[f].raw[: olen[f]] for f in range(n)]
+    dcap = [len(d) + 64 for d in datas]
+    douts = [C.create_string_buffer(c) for c in dcap]
+    fin = (C.c_char_p * n)(*frames)
+    flen = (C.c_size_t * n)(*[len(f) for f in frames])
+    doutp = (C.c_void_p * n)(*[C.cast(o, C.c_void_p) for o in douts])
+    dcapa = (C.c_size_t * n)(*dcap)
+    dlen = (C.c_size_t * n)()
+    used = (C.c_size_t * n)()
+    dst = (C.c_int * n)()
+    tds = []
+    for _ in range(3):
+        t = time.perf_counter()
+        rc = L.lzf_frame_decompress_many(n, fin, flen, None, 0, doutp, dcapa, dlen, used, dst)
+        tds.append(time.perf_counter() - t)
+        assert rc == 0 and not any(dst)
+    assert all(douts[f].raw[: dlen[f]] == datas[f] for f in range(0, n, 8))
+    res["frame_compress_many_gibs"] = round(total / sorted(tcs)[1] / 2**30, 3)
+    res["frame_decompress_many_gibs"] = round(total / sorted(tds)[1] / 2**30, 3)
+    return res
+
+
+# ======================================================================================= configs[3]
+def run_config4(args, torch, device, ffi, dist, rank, world, dev):
+    """8 GiB log-text stream, framed independent-blocks mode, block ranges sharded over the ranks, frame reassembled by all-gather."""
+    from rust_lz_fear_amd import dist as lzdist, framed
+    nblk_all = args.blocks
+    lo, hi = lzdist.shard_range(nblk_all, rank, world)
+    nloc = hi - lo
+    t0 = time.time()
+    # synthetic stream: 64 MiB of log_text generated, tile t of it rotated by a tile-specific number of bytes and its digits
+    # re-keyed (XOR with a tile byte on the low nibble of digit positions would break the text; a plain rotation keeps it log text)
+    base_blocks = 16
+    base = torch.from_numpy(synth.log_text(0, base_blocks * BS)).to(dev)
+    src = torch.empty(nloc * BS, dtype=torch.uint8, device=dev)
+    for i in range(nloc):
+        g = lo + i
+        tile, b = divmod(g, base_blocks)
+        blk = base[b * BS:(b + 1) * BS]
+        src[i * BS:(i + 1) * BS] = torch.roll(blk, (tile * 104729) % BS) if tile else blk
+    torch.cuda.synchronize()
+    log(f"[bench] rank {rank}: blocks [{lo}, {hi}) of {nblk_all} ({src.numel() / 2**30:.2f} GiB) in HBM ({time.time() - t0:.1f}s)")
+    comp = torch.empty(nloc * BS, dtype=torch.uint8, device=dev)
+    cj = np.zeros(nloc, dtype=device.CJOB)
+    cj["input"] = np.uint64(src.data_ptr()) + np.arange(nloc, dtype=np.uint64) * np.uint64(BS)
+    cj["input_len"] = BS
+    cj["out"] = np.uint64(comp.data_ptr()) + np.arange(nloc, dtype=np.uint64) * np.uint64(BS)
+    cj["out_cap"] = BS
+    cj["table_kind"] = ffi.TABLE_U32
+    d_cj = device.to_device(cj, dev)
+    d_cres = torch.zeros(nloc * 16, dtype=torch.uint8, device=dev)
+    frame_cap = 64 + nblk_all * (BS + 8)
+    frame = torch.empty(min(frame_cap, 64 + nblk_all * 8 + (nblk_all * BS) // 2), dtype=torch.uint8, device=dev)   # log text compresses > 2 x
+    state = {}
+    header = lzdist.frame_header(content_checksum=False, block_size=BS)
+
+    def step():
+        device.compress_batch(d_cj, d_cres, nloc, ffi.KINDS_U32)
+        state["frame_len"], state["comp_total"] = lzdist.gather_frame_device(d_cres, comp, src, BS, nloc, nblk_all, frame, dist, rank, world, device, header)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
     if dist:
-        dist.destroy_process_group()
-
-
-def cpu_baseline(comp2d, clen, lens, kidx, budget_s):
-    """The CPU restatement of lz-fear (oracle/, kind "port": the Rust reference cannot be built
-    here) timed on this host's cores over a bounded sample of the same blocks."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import ctypes as C
-    import oracle_ffi as o
-    L = o.lib()
-    cores = os.cpu_count() or 1
-    threads = min(cores, 32)
-    sample = kidx[: max(threads, min(len(kidx), 48))]
-    host = [(comp2d[int(i), : int(clen[i])].cpu().numpy().tobytes(), int(lens[i])) for i in sample]
-    # ---- decompress
-    def dec_one(item):
-        c, n = item
-        out = C.create_string_buffer(n + 64)
-        ln = C.c_size_t(0)
-        rc = L.lzfo_decompress_raw(c, len(c), b"", 0, out, C.byref(ln), n + 64, n)
-        assert rc == 0 and ln.value == n
-        return out
-    srcs = []
-    t0 = time.perf_counter()
-    with concurrent.futures.ThreadPoolExecutor(threads) as ex:
-        outs = list(ex.map(dec_one, host))
-    t_once = time.perf_counter() - t0
-    srcs = [o_.raw[:n] for o_, (_, n) in zip(outs, host)]
-    reps = max(1, int(budget_s * 0.4 / max(t_once, 1e-3)))
-    t0 = time.perf_counter()
-    with concurrent.futures.ThreadPoolExecutor(threads) as ex:
-        for _ in range(reps):
-            list(ex.map(dec_one, host))
-    t_dec = (time.perf_counter() - t0) / reps
-    nbytes = sum(n for _, n in host)
-    # ---- compress (same blocks)
-    def comp_one(s):
-        t = o.U32Table()
-        out = C.create_string_buffer(len(s) + 64)
-        ln = C.c_size_t(0)
-        L.lzfo_compress2(s, len(s), 0, 0, C.addressof(t), out, len(s), C.byref(ln))
-        return ln.value
-    t0 = time.perf_counter()
-    with concurrent.futures.ThreadPoolExecutor(threads) as ex:
-        list(ex.map(comp_one, srcs))
-    t_comp = time.perf_counter() - t0
-    return {"value": round(nbytes / t_dec / 2**30, 3), "unit": "GiB/s (decompress, uncompressed bytes)",
-            "cores": threads, "kind": "port",
-            "sample": f"{len(host)} of the same 4 MiB blocks ({nbytes / 2**20:.0f} MiB), {threads} threads, "
-                      f"{reps} reps; oracle/lzf_oracle.c (lz-fear restated in C, gcc -O3)",
-            "compress_value": round(nbytes / t_comp / 2**30, 3), "host_cpus": cores}
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t1
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed_max = float(t[0])
+    # ---- check: the frame's head == the oracle's frame of the same first blocks (rank 0 holds them)
+    verified = None
+    if rank == 0 and not args.no_verify:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_ffi as o
+        k = min(3, nloc)
+        host = src[: k * BS].cpu().numpy().tobytes()
+        rc, ref = o.frame_compress(host, settings=o.make_settings(content_checksum=False))
+        assert rc == 0
+        mine = frame[: len(ref)].cpu().numpy().tobytes()
+        body = ref[:-4]                                                # (without the oracle frame's EndMark)
+        verified = mine[: len(body)] == body
+        assert verified, "sharded frame differs from the oracle's frame on the first blocks"
+    if rank != 0:
+        return None
+    total_bytes = float(nblk_all) * BS
+    wire = state["comp_total"] * (world - 1) / max(world, 1)
+    return {
+        "metric": METRIC,
+        "value": round(total_bytes * args.steps / elapsed_max / 2**30, 3), "unit": "GiB/s (uncompressed bytes compressed into one frame per second)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed_max / args.steps * 1e3, 4),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "config4: log_text stream of %d x 4 MiB blocks (%.1f GiB), framed independent-blocks mode (content checksum "
+                               "off: XXH32 of the whole stream is one serial chain), blocks sharded by contiguous ranges, size table + "
+                               "payload all-gather and frame assembly inside the timed region; lz4 ratio %.2f" %
+                               (nblk_all, total_bytes / 2**30, total_bytes / max(state["comp_total"], 1)),
+                   "blocks": nblk_all, "block_size": BS, "parallelism": f"block ranges x{world}, all-gather over RCCL",
+                   "frame_bytes": int(state["frame_len"]), "wire_bytes_in_per_rank": int(wire), "verified_against_oracle_prefix": verified},
+    }
 
 
 if __name__ == "__main__":

@@ -78,3 +78,74 @@ def assemble_frame(settings, payloads, comp_len, raw_len, content_xxh32):
     if rc != 0:
         raise ffi.LzfError(rc, "lzf_frame_assemble failed")
     return out.raw[: outlen.value]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Device path (BASELINE config 4, bench.py --workload config4): everything stays in HBM, no per-block Python.
+# A rank's part of the frame body — [u32 size word][payload] per block of its range — is contiguous in the frame,
+# so every rank packs its own segment straight into the frame buffer at its final offset and the exchange is one
+# exact-size send / receive per peer pair (the direct all-gather xGMI offers: every link carries one segment).
+# ------------------------------------------------------------------------------------------------------------------
+def frame_header(content_checksum=False, block_size=4 << 20, independent=True, block_checksums=False):
+    """Header bytes of a frame without content size / dictionary id (src/framed/compress.rs:163-200, header.rs:30-81):
+    magic, FLG, BD, HC = second byte of XXH32(FLG BD)."""
+    code = {64 << 10: 4, 256 << 10: 5, 1 << 20: 6, 4 << 20: 7}[block_size]
+    flg = (1 << 6) | (int(independent) << 5) | (int(block_checksums) << 4) | (int(content_checksum) << 2)
+    desc = bytes([flg, code << 4])
+    hc = (ffi.lib().lzf_xxh32(desc, len(desc), 0) >> 8) & 0xFF
+    return bytes([0x04, 0x22, 0x4D, 0x18]) + desc + bytes([hc])
+
+
+def gather_frame_device(d_cres, comp, src, block_size, n_local, n_blocks, frame, dist_mod, rank, world, device_mod, header):
+    """Pack this rank's compressed (or stored) blocks into `frame` (uint8 CUDA tensor) at their final offsets, exchange the
+    segments, write header and EndMark.  d_cres: the lzf_job_result array of the rank's compress launch (HBM); comp: the
+    compressed slots (stride block_size); src: the rank's raw blocks.  Returns (frame bytes, total compressed payload bytes)."""
+    dev = frame.device
+    res = d_cres.view(torch.int64).view(-1, 2)[:n_local]
+    out_len = res[:, 0]
+    status = res[:, 1] & 0xFFFFFFFF
+    okm = status == ffi.OK                                        # else OutputFull: stored raw (framed/compress.rs:250-255)
+    plen = torch.where(okm, out_len, torch.full_like(out_len, block_size))
+    word = torch.where(okm, out_len, torch.full_like(out_len, block_size | 0x80000000))
+    max_blocks = (n_blocks + world - 1) // world
+    tab = torch.zeros(max_blocks, dtype=torch.int64, device=dev)
+    tab[:n_local] = plen
+    if world > 1:
+        tabs = torch.empty(world * max_blocks, dtype=torch.int64, device=dev)
+        dist_mod.all_gather_into_tensor(tabs, tab)                 # the size table
+        tabs = tabs.view(world, max_blocks)
+    else:
+        tabs = tab.view(1, max_blocks)
+    seg = (tabs + 4 * (tabs > 0)).sum(dim=1)                       # bytes of every rank's segment (a block's payload is never empty)
+    seg_host = seg.cpu().tolist()                                  # (one small device -> host copy: tensor slices need Python ints)
+    hl = len(header)
+    seg_off = [hl]
+    for r in range(world):
+        seg_off.append(seg_off[-1] + int(seg_host[r]))
+    flen = seg_off[-1] + 4
+    assert flen <= frame.numel(), "frame buffer too small"
+    # ---- this rank's segment, in place
+    base = seg_off[rank]
+    boff = base + torch.cumsum(plen + 4, 0) - (plen + 4)           # where block i's size word goes
+    idx = (boff[:, None] + torch.arange(4, device=dev)[None, :]).reshape(-1)
+    wb = ((word[:, None] >> (8 * torch.arange(4, device=dev))[None, :]) & 0xFF).to(torch.uint8).reshape(-1)
+    frame[idx] = wb
+    i64 = torch.arange(n_local, dtype=torch.int64, device=dev)
+    sp = torch.where(okm, comp.data_ptr() + i64 * block_size, src.data_ptr() + i64 * block_size)
+    dp = frame.data_ptr() + boff + 4
+    device_mod.copy_ranges(sp, dp, plen, n_local, block_size)
+    # ---- exchange: my segment to every peer, theirs into their places
+    if world > 1:
+        ops = []
+        mine = frame[seg_off[rank]:seg_off[rank + 1]]
+        for p in range(world):
+            if p == rank:
+                continue
+            ops.append(dist_mod.P2POp(dist_mod.isend, mine, p))
+            ops.append(dist_mod.P2POp(dist_mod.irecv, frame[seg_off[p]:seg_off[p + 1]], p))
+        for w in dist_mod.batch_isend_irecv(ops):
+            w.wait()
+    frame[:hl] = torch.tensor(list(header), dtype=torch.uint8, device=dev)
+    frame[flen - 4:flen] = 0                                       # EndMark (no content checksum in this mode)
+    comp_total = int(sum(seg_host)) - 4 * n_blocks
+    return flen, comp_total
