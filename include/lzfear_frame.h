@@ -13,6 +13,9 @@
  * lzf_decompress_batch of lzfear_hip.h); linked-block frames are inherently sequential and run
  * block after block with the table / window carried between calls.
  * Buffers are host memory.  No CPU codec: the calls fail with LZF_E_NO_DEVICE without a GPU.
+ * Checksums: the header checksum (a few bytes) is hashed on the host; block checksums are computed on the device for
+ * all blocks of a call in one launch; content checksums on the device for frames up to 32 MiB and on host worker
+ * threads, overlapping the kernels, for longer ones (XXH32 is one serial chain per buffer).
  */
 #ifndef LZFEAR_FRAME_H
 #define LZFEAR_FRAME_H
@@ -42,6 +45,8 @@ enum {
     LZF_F_INVALID_BLOCK_SIZE = 27,     /* CompressionError::InvalidBlockSize, compress.rs:21-22 */
     LZF_F_PANIC = 28                   /* BlockDescriptor::new unwrap() panic, header.rs:55 */
 };
+/* per-frame status of the *_many calls only: the frame alone asks for more device memory than the budget allows */
+#define LZF_E_NO_MEMORY (-4)
 
 #define LZF_MAGIC 0x184D2204u          /* src/framed/mod.rs:16 */
 #define LZF_WINDOW_SIZE 65536u         /* src/framed/mod.rs:20 */
@@ -99,6 +104,43 @@ int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint
 int lzf_frame_decompress_many(uint32_t n_frames, const uint8_t* const* in, const size_t* in_len,
                               const uint8_t* dict, size_t dict_len,
                               uint8_t* const* out, const size_t* out_cap, size_t* out_len, size_t* consumed, int* status);
+
+/* Block-by-block reader: LZ4FrameReader (src/framed/decompress.rs:79-282) over a memory buffer that the caller keeps
+ * alive.  lzf_frame_reader_new = LZ4FrameReader::new (:102-161, header errors as its return value, *r = NULL then);
+ * lzf_frame_reader_decode_block = decode_block (:198-282): decodes the next block into out[0..out_cap) — *out_len = 0
+ * with LZF_OK once the EndMark has been read (`finished`, :206-215; the content checksum is verified there) —
+ * with `dict` as the reference's `dictionary` argument (:238-245; linked frames carry their own 64 KiB window, :253-269).
+ * One block per call means one small launch per call: the *_many drivers above are the fast path, this is the
+ * reference's streaming interface for callers that want it.  Needs out_cap >= block_maxsize + the block's compressed
+ * size to never see LZF_OUT_CAPACITY. */
+typedef struct lzf_frame_reader lzf_frame_reader;
+int lzf_frame_reader_new(const uint8_t* in, size_t in_len, lzf_frame_reader** r);
+void lzf_frame_reader_free(lzf_frame_reader* r);
+void lzf_frame_reader_info(const lzf_frame_reader* r, lzf_frame_info* info);     /* block_size(), frame_size(), dictionary_id() :167-175 */
+int lzf_frame_reader_decode_block(lzf_frame_reader* r, const uint8_t* dict, size_t dict_len,
+                                  uint8_t* out, size_t out_cap, size_t* out_len);
+int lzf_frame_reader_finished(const lzf_frame_reader* r);
+size_t lzf_frame_reader_consumed(const lzf_frame_reader* r);                     /* bytes of `in` read so far */
+
+/* ---- the host side of the drivers (host_staging.h): one pinned slab, kept device scratch, worker threads ---------- */
+typedef struct lzf_frame_stats {
+    uint64_t calls;                     /* *_many calls served */
+    uint64_t device_block_hashes;       /* block checksums computed by lzf_xxh32_batch */
+    uint64_t host_block_hashes;         /* ... by the host (lzf_frame_assemble only: its payloads are host memory) */
+    uint64_t device_content_hashes;     /* content checksums: one device chain per frame (frames <= 32 MiB) */
+    uint64_t host_content_hashes;       /* ... on the worker threads (longer frames) */
+    uint64_t h2d_copies, d2h_copies;    /* DMA transfers issued through the pinned slab, and their bytes */
+    uint64_t h2d_bytes, d2h_bytes;
+    uint64_t pinned_bytes;              /* size of the pinned slab now */
+} lzf_frame_stats;
+void lzf_frame_get_stats(lzf_frame_stats* st);
+/* The drivers keep their pinned slab and device scratch between calls (allocating gigabytes costs more than the
+ * kernels); this gives everything back.  Calls are serialised per process. */
+void lzf_frame_release_scratch(void);
+void lzf_frame_set_host_threads(uint32_t n);      /* memcpy / hashing workers, 0 = default (12 on a large host) */
+/* Device memory one pass of lzf_frame_decompress_many may use (0 = half of what is free): more frames than fit are
+ * processed in several passes; a frame that does not fit alone gets status LZF_E_NO_MEMORY. */
+void lzf_frame_set_memory_budget(size_t bytes);
 
 /* XXH32 on the host (header / content checksums; twox-hash XxHash32 in the reference). */
 uint32_t lzf_xxh32(const uint8_t* p, size_t len, uint32_t seed);

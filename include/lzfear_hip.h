@@ -14,7 +14,8 @@
  *
  * Memory: every pointer in a job is a DEVICE pointer (HBM) unless the function name ends in
  * `_host`.  The library never retains pointers past a call and owns no global state besides
- * lazily created scratch for the `_host` helpers.  There is NO CPU fallback: every entry point
+ * the staging memory of the `_host` helpers and the frame layer (one pinned slab and device
+ * scratch, kept between calls; lzf_frame_release_scratch() of lzfear_frame.h frees them).  There is NO CPU fallback: every entry point
  * returns LZF_E_NO_DEVICE when no HIP device is usable.
  */
 #ifndef LZFEAR_HIP_H
@@ -118,9 +119,15 @@ int lzf_device_count(void);
  * d_jobs / d_results are device arrays of n_jobs entries.  Asynchronous on `hip_stream`
  * (a hipStream_t; NULL = the legacy default stream) of the CURRENT device.
  * `table_kinds` says which table types occur in the batch (the job array lives in HBM, the
- * host cannot look): LZF_KINDS_U32, LZF_KINDS_U16 or both or'ed; 0 means "either". */
+ * host cannot look): LZF_KINDS_U32, LZF_KINDS_U16 or both or'ed; 0 means "either".
+ * Batches larger than the device holds at once are executed longest job first (an internal launch order: results[i]
+ * always belongs to jobs[i]). */
 #define LZF_KINDS_U32 1u
 #define LZF_KINDS_U16 2u
+/* optional promise, or'ed in: every U32 job of the batch has table == NULL or a LZF_CJOB_TABLE_READONLY table whose
+ * offset is 0, and cursor <= input_len < 2 GiB (the independent-block jobs of src/framed/compress.rs:265-270).  Saves the
+ * launch of the general kernel; a job that breaks the promise reports LZF_CONTRACT. */
+#define LZF_KINDS_U32_FRESH_ONLY 4u
 int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results,
                        uint32_t n_jobs, uint32_t table_kinds, void* hip_stream);
 
@@ -179,6 +186,8 @@ int lzf_copy_ranges(const uint8_t* const* d_src, uint8_t* const* d_dst, const ui
  * place.  Used by the frame layer and by callers that have not moved their data to HBM. */
 int lzf_compress_batch_host(const lzf_compress_job* jobs, lzf_job_result* results, uint32_t n_jobs);
 int lzf_decompress_batch_host(const lzf_decompress_job* jobs, lzf_job_result* results, uint32_t n_jobs);
+/* lzf_xxh32_batch over host buffers (staged to the device, hashed there; `out` is a host array). */
+int lzf_xxh32_batch_host(const uint8_t* const* ptrs, const uint64_t* lens, uint32_t* out, uint32_t n);
 
 #ifdef __cplusplus
 }

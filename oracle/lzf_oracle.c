@@ -104,7 +104,7 @@ int lzfo_compress2(const uint8_t* input, size_t len, size_t cursor, int kind, vo
     int contract = 0;
     size_t limit = kind == LZFO_TABLE_U16 ? 0xFFFFu : 0xFFFFFFFFull;   /* :75, :100 */
     *out_len = 0;
-    if (len > limit || cursor > len) return LZFO_CONTRACT;             /* :167 */
+    if (len > limit) return LZFO_CONTRACT;                             /* :167 (cursor >= len: the loop at :171 never runs -> Ok, nothing written) */
 
 #define REPLACE(pos) (kind == LZFO_TABLE_U16                                          \
         ? lzfo_u16_replace((lzfo_u16_table*)table, input, len, (pos), &contract)      \

@@ -1,28 +1,38 @@
 """Build recipe for liblzfear_hip.so (hipcc, gfx950 only).  In-tree output so that the
-library travels with the repo snapshot to the GPU box."""
+library travels with the repo snapshot to the GPU box.
+
+Two flavours from the same sources:
+  product   liblzfear_hip.so            the kernels the C ABI launches, no environment knobs
+  analysis  liblzfear_hip_analysis.so   -DLZF_ANALYSIS: every kernel generation kept for A/B runs and counter
+                                        studies (tools/, the variant parity test), selected with LZF_DECOMPRESS_KERNEL
+                                        / LZF_COMPRESS_KERNEL / LZF_*_ORDER
+Objects are compiled one source per hipcc process, in parallel, into rust-lz-fear_amd/_obj/<flavour>/.
+"""
+import hashlib
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 ROOT = os.path.dirname(PKG_DIR)
-LIB_PATH = os.environ.get("LZF_LIB_PATH") or os.path.join(PKG_DIR, "liblzfear_hip.so")   # override: debug builds only
+LIB_PATH = os.environ.get("LZF_LIB_PATH") or os.path.join(PKG_DIR, "liblzfear_hip.so")   # override: analysis builds only
+ANALYSIS_LIB_PATH = os.path.join(PKG_DIR, "liblzfear_hip_analysis.so")
 
-HIP_SOURCES = ["capi.hip", "lz4_decompress.hip", "lz4_decompress_batched.hip", "lz4_decompress_windowed.hip", "lz4_decompress_paired.hip", "lz4_decompress_walk.hip", "lz4_decompress_v4.hip", "lz4_decompress_v5.hip", "lz4_decompress_v6.hip", "lz4_compress.hip", "lz4_compress_compact.hip", "aux_kernels.hip"]
-CXX_SOURCES = ["frame.cpp"]
-DEPS = HIP_SOURCES + CXX_SOURCES + ["kernels.h", "lzf_device.h", "lz4_decompress_batch_phase.inc", "lz4_decompress_parse_phase.inc", "lz4_decompress_walk_phase.inc", "lz4_decompress_copy2.inc", "lz4_decompress_copy3.inc", "lz4_decompress_gwalk_phase.inc", "lzf_copy_helpers.h", "lzf_parse_helpers.h", "lzf_compress_common.h", os.path.join(ROOT, "include", "lzfear_hip.h"),
-                                     os.path.join(ROOT, "include", "lzfear_frame.h")]
+PRODUCT_HIP = ["capi.hip", "lz4_decompress_batched.hip", "lz4_decompress_paired.hip", "lz4_compress.hip",
+               "lz4_compress_compact.hip", "aux_kernels.hip"]
+ANALYSIS_HIP = ["lz4_decompress.hip", "lz4_decompress_windowed.hip", "lz4_decompress_walk.hip", "lz4_decompress_v4.hip",
+                "lz4_decompress_v5.hip", "lz4_decompress_v6.hip"]
+CXX_SOURCES = ["frame.cpp", "host_staging.cpp"]
+HEADERS = ["kernels.h", "lzf_device.h", "lz4_decompress_batch_phase.inc", "lz4_decompress_parse_phase.inc",
+           "lz4_decompress_walk_phase.inc", "lz4_decompress_copy2.inc", "lz4_decompress_copy3.inc",
+           "lz4_decompress_gwalk_phase.inc", "lzf_copy_helpers.h", "lzf_parse_helpers.h", "lzf_compress_common.h",
+           "host_staging.h",
+           os.path.join(ROOT, "include", "lzfear_hip.h"), os.path.join(ROOT, "include", "lzfear_frame.h")]
 
 
-def _stale():
-    if not os.path.exists(LIB_PATH):
-        return True
-    t = os.path.getmtime(LIB_PATH)
-    for d in DEPS:
-        p = d if os.path.isabs(d) else os.path.join(CSRC, d)
-        if os.path.exists(p) and os.path.getmtime(p) > t:
-            return True
-    return False
+def _path(d):
+    return d if os.path.isabs(d) else os.path.join(CSRC, d)
 
 
 def hipcc():
@@ -32,15 +42,59 @@ def hipcc():
     return "hipcc"
 
 
-def build_library(force=False, verbose=False, defines=(), out=None):
-    """hipcc --offload-arch=gfx950 -> rust-lz-fear_amd/liblzfear_hip.so"""
-    out = out or LIB_PATH
-    if not force and not defines and not _stale():
-        return out
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I", os.path.join(ROOT, "include"), "-o", out] + [f"-D{d}" for d in defines]
-    cmd += [os.path.join(CSRC, s) for s in HIP_SOURCES + CXX_SOURCES]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.check_call(cmd)
+def _sources(analysis):
+    return PRODUCT_HIP + (ANALYSIS_HIP if analysis else []) + CXX_SOURCES
+
+
+def _newest_header():
+    return max((os.path.getmtime(_path(h)) for h in HEADERS if os.path.exists(_path(h))), default=0.0)
+
+
+def build_library(force=False, verbose=False, defines=(), out=None, analysis=False):
+    """hipcc --offload-arch=gfx950 -> rust-lz-fear_amd/liblzfear_hip.so (or `out`)."""
+    defines = list(defines)
+    if (analysis or any(d.startswith("LZF_DBG") for d in defines)) and "LZF_ANALYSIS" not in defines:
+        defines.append("LZF_ANALYSIS")
+    analysis = "LZF_ANALYSIS" in defines
+    out = out or (ANALYSIS_LIB_PATH if analysis else LIB_PATH)
+    srcs_t = max([os.path.getmtime(_path(s)) for s in _sources(analysis)] + [_newest_header()])
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= srcs_t:
+        return out                                  # (also the GPU box's case: the built library travels, the objects do not)
+    tag = "product" if not defines else hashlib.sha1(" ".join(sorted(defines)).encode()).hexdigest()[:12]
+    objdir = os.path.join(PKG_DIR, "_obj", tag)
+    os.makedirs(objdir, exist_ok=True)
+    hdr_t = _newest_header()
+    base = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include")] + [f"-D{d}" for d in defines]
+    jobs = []
+    for s in _sources(analysis):
+        src = _path(s)
+        obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
+        stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t)
+        jobs.append((src, obj, stale))
+    todo = [(s, o) for s, o, st in jobs if st]
+
+    def compile_one(so):
+        cmd = base + ["-c", so[0], "-o", so[1]]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 4)) as ex:
+            list(ex.map(compile_one, todo))
+    objs = [o for _, o, _ in jobs]
+    if todo or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(o) for o in objs):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-lpthread"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
     return out
+
+
+def build_analysis_library(force=False, verbose=False):
+    return build_library(force=force, verbose=verbose, analysis=True)
+
+
+if __name__ == "__main__":
+    import sys
+    print(build_library(force="--force" in sys.argv, verbose=True, analysis="--analysis" in sys.argv))

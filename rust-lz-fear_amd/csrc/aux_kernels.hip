@@ -49,6 +49,52 @@ __global__ __launch_bounds__(64) void lzf_xxh32_kernel(const uint8_t* const* __r
     }
 }
 
+// The same hash with one wavefront per buffer, for long buffers (content checksums, the checksums of 4 MiB blocks): the kernel
+// above keeps only 64 bytes per hash in flight, which is dependent-load latency all the way.  Here the wave fetches 1 KiB per
+// step with coalesced 16-byte loads, two steps ahead, multiplies by PRIME2 in all 64 lanes at once and parks the products in
+// LDS; lanes 0..3 then run the serial chain (add, rotate, multiply — ~30 cycles a stripe, ~1.3 GB/s per hash) on LDS reads
+// that do not depend on the chain.  The chip runs thousands of such chains at once.
+__global__ __launch_bounds__(64) void lzf_xxh32_wave_kernel(const uint8_t* const* __restrict__ ptrs,
+                                                            const uint64_t* __restrict__ lens,
+                                                            uint32_t* __restrict__ out, uint32_t n) {
+    __shared__ __attribute__((aligned(16))) uint32_t buf[2][256];
+    const uint32_t g = blockIdx.x;
+    if (g >= n) return;
+    const uint32_t lane = threadIdx.x, q = lane & 3u;
+    cgu8* p = as_global(ptrs[g]);
+    const uint64_t len = lens[g];
+    uint32_t v = q == 0 ? XP1 + XP2 : q == 1 ? XP2 : q == 2 ? 0u : 0u - XP1;
+    const uint64_t chunks = len >> 10;
+    const u32x4 zero = {0u, 0u, 0u, 0u};
+    u32x4 r0 = chunks > 0 ? ld16(p + lane * 16u) : zero;
+    u32x4 r1 = chunks > 1 ? ld16(p + 1024u + lane * 16u) : zero;
+    for (uint64_t c = 0; c < chunks; ++c) {
+        uint32_t* b = buf[c & 1u];
+        *reinterpret_cast<u32x4*>(b + lane * 4u) = r0 * XP2;
+        r0 = r1;
+        r1 = c + 2 < chunks ? ld16(p + (c + 2) * 1024u + lane * 16u) : zero;
+        __syncthreads();                               // (one wave: orders the LDS writes before the reads for the compiler)
+#pragma unroll 16
+        for (uint32_t s = 0; s < 64u; ++s) v = rotl32(v + b[s * 4u + q], 13) * XP1;
+    }
+    const uint64_t stripes = len >> 4;
+    cgu8* sp = p + q * 4u;
+    for (uint64_t s = chunks << 6; s < stripes; ++s) v = xround(v, ld4(sp + s * 16));
+    const uint32_t r = q == 0 ? rotl32(v, 1) : q == 1 ? rotl32(v, 7) : q == 2 ? rotl32(v, 12) : rotl32(v, 18);
+    uint32_t h = r + __shfl_xor(r, 1);
+    h = h + __shfl_xor(h, 2);
+    if (lane == 0) {
+        if (len < 16) h = XP5;   // seed + PRIME5
+        h += (uint32_t)len;
+        cgu8* t = p + (stripes << 4);
+        uint32_t rem = (uint32_t)(len & 15u);
+        while (rem >= 4) { h = rotl32(h + ld4(t) * XP3, 17) * XP4; t += 4; rem -= 4; }
+        while (rem) { h = rotl32(h + (uint32_t)(*t) * XP5, 11) * XP1; ++t; --rem; }
+        h ^= h >> 15; h *= XP2; h ^= h >> 13; h *= XP3; h ^= h >> 16;
+        out[g] = h;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Template-table seeding — src/framed/compress.rs:202-211:
 //   for window in dict.windows(8).step_by(3) { template_table.replace(dict, offset) }
@@ -90,7 +136,10 @@ __global__ __launch_bounds__(256) void lzf_chain_decompress_step_kernel(const lz
     const uint32_t i = blockIdx.x;
     if (i >= n) return;
     const lzf_chain_step st = steps[i];
-    lzf_chain_state cs = state[i];
+    __shared__ lzf_chain_state cs_in;                              // read once: lane 0 stores the new state below while other waves may not have started
+    if (threadIdx.x == 0) cs_in = state[i];
+    __syncthreads();
+    lzf_chain_state cs = cs_in;
     if (st.prev_job != 0xFFFFFFFFu && !cs.dead) {                 // finish the previous step (decompress.rs:253-269: the output joins the history)
         const lzf_job_result r = results[st.prev_job];
         if (r.status != LZF_OK) cs.dead = 1u;

@@ -9,7 +9,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <chrono>
+#include <cstdio>
+#include <mutex>
 #include "../../include/lzfear_frame.h"
+#include "host_staging.h"
 
 namespace {
 
@@ -97,15 +101,19 @@ int seeded_template(const uint8_t* dict, size_t dict_len, lzf_u32_table* host_ta
     return rc;
 }
 
+uint64_t g_host_block_hashes = 0, g_reader_device_hashes = 0;
+size_t g_budget = 0;     // lzf_frame_set_memory_budget (0: half of the free device memory)
+
 // One block of a frame as the scan finds it (decompress.rs:217-235).
-struct Blk { const uint8_t* data; uint32_t len; bool compressed; };
+struct Blk { const uint8_t* data; uint32_t len; bool compressed; uint32_t want_sum; size_t end_off; };   // want_sum: the checksum behind it; end_off: input read once it is
 struct FrameScan {
     size_t consumed = 0;          // bytes of the input read
     int err = LZF_OK;             // structural error that ends the scan (reported in stream order)
     bool endmark = false;
     uint32_t want_content = 0;    // content checksum behind the EndMark
 };
-// The u32 length hops over a frame's blocks (decompress.rs:205-235), block checksums verified on the way.
+// The u32 length hops over a frame's blocks (decompress.rs:205-235).  Block checksums are only collected here: the
+// device hashes all blocks of a call in one launch and the delivery loop compares, in stream order.
 void scan_blocks(const uint8_t* in, size_t in_len, const lzf_frame_info& fi, std::vector<Blk>& blocks, FrameScan& sc) {
     const size_t bmax = (size_t)fi.block_maxsize;
     const bool bsum = fi.flags & FL_BLOCKSUM, csum = fi.flags & FL_CSUM;
@@ -121,13 +129,12 @@ void scan_blocks(const uint8_t* in, size_t in_len, const lzf_frame_info& fi, std
         if (bl > (uint32_t)bmax) { sc.err = LZF_F_BLOCK_SIZE_OVERFLOW; break; }               // :220-222
         if (in_len - r < bl) { sc.err = LZF_F_INPUT_ERROR; r = in_len; break; }               // :226
         const uint8_t* data = in + r; r += bl;
-        if (bsum) {                                                                           // :228-235
+        uint32_t c = 0;
+        if (bsum) {                                                                           // :228-230
             if (in_len - r < 4) { sc.err = LZF_F_INPUT_ERROR; r = in_len; break; }
-            const uint32_t c = rd32(in + r); r += 4;
-            Xxh32 h; h.update(data, bl);
-            if (c != h.digest()) { sc.err = LZF_F_BLOCK_CHECKSUM_FAIL; break; }
+            c = rd32(in + r); r += 4;
         }
-        blocks.push_back({data, bl, compressed});
+        blocks.push_back({data, bl, compressed, c, r});
     }
     sc.consumed = r;
 }
@@ -182,7 +189,7 @@ int lzf_frame_assemble(const lzf_settings* s, uint32_t n_blocks, const uint8_t* 
         const uint32_t n = stored ? raw_len[i] : comp_len[i];
         wr32(out + w, stored ? (n | INCOMPRESSIBLE) : n); w += 4;              // compress.rs:247,253
         memcpy(out + w, payload[i], n);                                        // :258
-        if (s->block_checksums) { wr32(out + w + n, lzf_xxh32(out + w, n, 0)); }   // :259-263
+        if (s->block_checksums) { wr32(out + w + n, lzf_xxh32(out + w, n, 0)); ++g_host_block_hashes; }   // :259-263 (host payloads: host hash)
         w += n + (s->block_checksums ? 4 : 0);
     }
     wr32(out + w, 0); w += 4;                                                  // :277 EndMark
@@ -199,29 +206,37 @@ int lzf_frame_compress(const lzf_settings* s, const uint8_t* in, size_t in_len, 
     return rc != LZF_OK ? rc : st;
 }
 
-// decompress.rs:102-161
-int lzf_frame_read_header(const uint8_t* in, size_t in_len, lzf_frame_info* info) {
+// decompress.rs:102-161; *consumed = bytes the reference's reader has read when it returns
+static int read_header_ex(const uint8_t* in, size_t in_len, lzf_frame_info* info, size_t* consumed) {
     memset(info, 0, sizeof *info);
     size_t r = 0;
-#define NEED(n) do { if (in_len - r < (size_t)(n)) return LZF_F_INPUT_ERROR; } while (0)
-    NEED(4); if (rd32(in) != LZF_MAGIC) return LZF_F_WRONG_MAGIC; r = 4;     // :103-106
+    int rc = LZF_OK;
+#define NEED(n) do { if (in_len - r < (size_t)(n)) { r = in_len; rc = LZF_F_INPUT_ERROR; goto done; } } while (0)
+#define FAIL(c) do { rc = (c); goto done; } while (0)
+    {
+    NEED(4); r = 4; if (rd32(in) != LZF_MAGIC) FAIL(LZF_F_WRONG_MAGIC);       // :103-106
     NEED(1); const uint8_t flg = in[r++];
-    if ((flg >> 6) != 1) return LZF_F_UNSUPPORTED_VERSION;                    // header.rs:33-36
-    if (flg & 0x02) return LZF_F_RESERVED_FLAG_BITS;                          // header.rs:37-39
+    if ((flg >> 6) != 1) FAIL(LZF_F_UNSUPPORTED_VERSION);                     // header.rs:33-36
+    if (flg & 0x02) FAIL(LZF_F_RESERVED_FLAG_BITS);                           // header.rs:37-39
     NEED(1); const uint8_t bd = in[r++];
-    if (bd & 0x8F) return LZF_F_RESERVED_BD_BITS;                             // header.rs:66-68
+    if (bd & 0x8F) FAIL(LZF_F_RESERVED_BD_BITS);                              // header.rs:66-68
     info->flags = flg; info->bd = bd;
     if (flg & FL_CSIZE) { NEED(8); info->has_content_size = 1; info->content_size = (uint64_t)rd32(in + r) | ((uint64_t)rd32(in + r + 4) << 32); r += 8; }
     if (flg & FL_DICTID) { NEED(4); info->has_dictionary_id = 1; info->dictionary_id = rd32(in + r); r += 4; }
     NEED(1); const uint8_t hc = in[r++];
-    if (hc != (uint8_t)(lzf_xxh32(in + 4, r - 5, 0) >> 8)) return LZF_F_HEADER_CHECKSUM_FAIL;   // :132-136
+    if (hc != (uint8_t)(lzf_xxh32(in + 4, r - 5, 0) >> 8)) FAIL(LZF_F_HEADER_CHECKSUM_FAIL);   // :132-136
     const unsigned size = (bd >> 4) & 7;
-    if (size < 4) return LZF_F_UNIMPLEMENTED_BLOCKSIZE;                       // :153, header.rs:73-80
+    if (size < 4) FAIL(LZF_F_UNIMPLEMENTED_BLOCKSIZE);                        // :153, header.rs:73-80
     info->block_maxsize = 1ull << (size * 2 + 8);
     info->header_len = (uint16_t)r;
-    return LZF_OK;
+    }
+done:
+    if (consumed) *consumed = r;
+    return rc;
 #undef NEED
+#undef FAIL
 }
+int lzf_frame_read_header(const uint8_t* in, size_t in_len, lzf_frame_info* info) { return read_header_ex(in, in_len, info, nullptr); }
 
 // decompress.rs:198-288 — one frame = a batch of one (lzf_frame_decompress_many below)
 int lzf_frame_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, size_t dict_len,
@@ -232,6 +247,122 @@ int lzf_frame_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, 
     return rc != LZF_OK ? rc : st;
 }
 
+// ---- the block-by-block reader: LZ4FrameReader (decompress.rs:79-282) ------------------------------------------------
+}  // extern "C"
+struct lzf_frame_reader {
+    const uint8_t* in; size_t in_len, pos;
+    lzf_frame_info fi;
+    bool finished = false, has_hasher = false, linked = false;
+    Xxh32 hasher{0};                    // content_hasher :89,:140-142
+    std::vector<uint8_t> window;        // carryover_window :90,:144-148
+};
+extern "C" {
+
+int lzf_frame_reader_new(const uint8_t* in, size_t in_len, lzf_frame_reader** r) {
+    if (!r) return LZF_E_INVALID;
+    *r = nullptr;
+    lzf_frame_info fi;
+    const int rc = lzf_frame_read_header(in, in_len, &fi);
+    if (rc != LZF_OK) return rc;
+    lzf_frame_reader* rd = new lzf_frame_reader;
+    rd->in = in; rd->in_len = in_len; rd->pos = fi.header_len; rd->fi = fi;
+    rd->has_hasher = (fi.flags & FL_CSUM) != 0; rd->linked = !(fi.flags & FL_INDEP);
+    *r = rd;
+    return LZF_OK;
+}
+void lzf_frame_reader_free(lzf_frame_reader* r) { delete r; }
+void lzf_frame_reader_info(const lzf_frame_reader* r, lzf_frame_info* info) { *info = r->fi; }
+int lzf_frame_reader_finished(const lzf_frame_reader* r) { return r->finished ? 1 : 0; }
+size_t lzf_frame_reader_consumed(const lzf_frame_reader* r) { return r->pos; }
+
+int lzf_frame_reader_decode_block(lzf_frame_reader* r, const uint8_t* dict, size_t dict_len, uint8_t* out, size_t out_cap, size_t* out_len) {
+    if (!r || !out_len || (!out && out_cap)) return LZF_E_INVALID;
+    *out_len = 0;
+    if (!dict) dict_len = 0;
+    if (r->finished) return LZF_OK;                                             // :202
+#define NEED(n) do { if (r->in_len - r->pos < (size_t)(n)) { r->pos = r->in_len; return LZF_F_INPUT_ERROR; } } while (0)
+    NEED(4); uint32_t bl = rd32(r->in + r->pos); r->pos += 4;                   // :205
+    if (bl == 0) {                                                              // :206-215
+        if (r->has_hasher) {
+            r->has_hasher = false;                                              // content_hasher.take()
+            NEED(4); const uint32_t c = rd32(r->in + r->pos); r->pos += 4;
+            if (c != r->hasher.digest()) return LZF_F_FRAME_CHECKSUM_FAIL;
+        }
+        r->finished = true;
+        return LZF_OK;
+    }
+    const bool compressed = (bl & INCOMPRESSIBLE) == 0; bl &= ~INCOMPRESSIBLE;  // :217-218
+    const size_t bmax = (size_t)r->fi.block_maxsize;
+    if (bl > (uint32_t)bmax) return LZF_F_BLOCK_SIZE_OVERFLOW;                  // :220-222
+    NEED(bl); const uint8_t* data = r->in + r->pos; r->pos += bl;               // :224-226
+    uint32_t want = 0; const bool bsum = (r->fi.flags & FL_BLOCKSUM) != 0;
+    if (bsum) { NEED(4); want = rd32(r->in + r->pos); r->pos += 4; }            // :229
+#undef NEED
+    // the prefix (:238-245)
+    const uint8_t* prefix = dict; size_t prefix_len = dict_len;
+    if (r->linked) {
+        if (r->window.empty() && dict_len) r->window.assign(dict, dict + dict_len);
+        prefix = r->window.data(); prefix_len = r->window.size();
+    }
+    // the block goes to the device once: checksum (:228-235) and decode (:247-251) both read it there
+    lzf_host::Staging& sg = lzf_host::Staging::get();
+    std::lock_guard<std::mutex> guard(sg.lock());
+    hipStream_t cs = sg.stream(0);
+    const size_t cap = bmax + bl;                                               // limit + what the literals may overshoot
+    uint8_t* d_in = static_cast<uint8_t*>(sg.device(0, (size_t)bl + 8));
+    uint8_t* d_out = static_cast<uint8_t*>(sg.device(1, cap));
+    uint8_t* d_pre = static_cast<uint8_t*>(sg.device(10, prefix_len));
+    uint8_t* d_meta = static_cast<uint8_t*>(sg.device(5, 1024));
+    if (!cs || !d_in || !d_out || !d_pre || !d_meta) return LZF_E_HIP;
+#define HIPR(e) do { if ((e) != hipSuccess) { (void)hipDeviceSynchronize(); return LZF_E_HIP; } } while (0)
+    HIPR(hipMemcpyAsync(d_in, data, bl, hipMemcpyHostToDevice, cs));
+    if (bsum) {
+        struct { const uint8_t* p; uint64_t n; uint32_t h; } m = {d_in, bl, 0};
+        HIPR(hipMemcpyAsync(d_meta, &m, sizeof m, hipMemcpyHostToDevice, cs));
+        int rc = lzf_xxh32_batch(reinterpret_cast<const uint8_t* const*>(d_meta), reinterpret_cast<const uint64_t*>(d_meta + 8), reinterpret_cast<uint32_t*>(d_meta + 16), 1, cs);
+        if (rc != LZF_OK) return rc;
+        uint32_t got = 0;
+        HIPR(hipMemcpyAsync(&got, d_meta + 16, 4, hipMemcpyDeviceToHost, cs));
+        HIPR(hipStreamSynchronize(cs));
+        ++g_reader_device_hashes;
+        if (got != want) return LZF_F_BLOCK_CHECKSUM_FAIL;
+    }
+    size_t n = 0;
+    if (compressed) {                                                           // :247-248
+        if (prefix_len) HIPR(hipMemcpyAsync(d_pre, prefix, prefix_len, hipMemcpyHostToDevice, cs));
+        lzf_decompress_job j; memset(&j, 0, sizeof j);
+        j.input = d_in; j.input_len = bl; j.prefix = d_pre; j.prefix_len = prefix_len; j.out = d_out; j.out_cap = cap; j.output_limit = bmax;
+        lzf_job_result res; memset(&res, 0, sizeof res);
+        HIPR(hipMemcpyAsync(d_meta + 64, &j, sizeof j, hipMemcpyHostToDevice, cs));
+        int rc = lzf_decompress_batch(reinterpret_cast<lzf_decompress_job*>(d_meta + 64), reinterpret_cast<lzf_job_result*>(d_meta + 256), 1, cs);
+        if (rc != LZF_OK) return rc;
+        HIPR(hipMemcpyAsync(&res, d_meta + 256, sizeof res, hipMemcpyDeviceToHost, cs));
+        HIPR(hipStreamSynchronize(cs));
+        if (res.status != LZF_OK) return res.status;                            // CodecError
+        n = (size_t)res.out_len;
+        if (n > out_cap) return LZF_OUT_CAPACITY;
+        if (n) { HIPR(hipMemcpyAsync(out, d_out, n, hipMemcpyDeviceToHost, cs)); HIPR(hipStreamSynchronize(cs)); }
+    } else {                                                                    // :249-251
+        n = bl;
+        if (n > out_cap) return LZF_OUT_CAPACITY;
+        HIPR(hipStreamSynchronize(cs));
+        memcpy(out, data, n);
+    }
+#undef HIPR
+    *out_len = n;
+    if (r->linked) {                                                            // :253-269
+        std::vector<uint8_t>& w = r->window;
+        if (n < LZF_WINDOW_SIZE) {
+            const size_t avail = w.size() + n;
+            if (avail >= LZF_WINDOW_SIZE) w.erase(w.begin(), w.begin() + (avail - LZF_WINDOW_SIZE));
+            w.insert(w.end(), out, out + n);
+        } else w.assign(out + n - LZF_WINDOW_SIZE, out + n);
+    }
+    if (n > bmax) return LZF_F_BLOCK_SIZE_OVERFLOW;                             // :272-274
+    if (r->has_hasher) r->hasher.update(out, n);                                // :276-278
+    return LZF_OK;
+}
+
 // =====================================================================================================================
 // Many frames per call.  One frame of a few large blocks leaves the chip almost empty (one wavefront per block); the
 // batch entry points want thousands of blocks.  These drivers put every block of every frame into the same launches
@@ -240,19 +371,84 @@ int lzf_frame_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, 
 // between (the jobs of all steps are known up front on the compress side — the window is input data and the table
 // lives on the device; on the decompress side lzf_chain_decompress_step patches each stream's length on the device).
 // Same bytes and the same statuses as calling lzf_frame_compress / lzf_frame_decompress once per frame.
+//
+// Data movement (host_staging.h): the caller's buffers go through one pinned slab in 4 MiB pieces, worker threads doing the
+// memcpy while the calling thread issues one asynchronous DMA per finished piece; results come back the same way from a
+// buffer the device has packed (lzf_copy_ranges), so only the bytes that are part of the result cross PCIe.  Block
+// checksums (compress.rs:259-263, decompress.rs:228-235) are computed by lzf_xxh32_batch on the device for all blocks at
+// once; content checksums (compress.rs:233-235,279-281; decompress.rs:207-211,276-278) likewise for frames up to
+// kDeviceHashMax bytes — XXH32 is one serial chain per buffer, ~1.3 GB/s per chain on the GPU but thousands of chains at
+// once, against ~6 GB/s on one host core — and on worker threads (one frame per thread, overlapping the kernels) beyond.
 // =====================================================================================================================
 }  // extern "C"
 namespace {
-struct DBuf {
-    void* p = nullptr;
-    ~DBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t n) { return hipMalloc(&p, n ? n : 1) == hipSuccess ? LZF_OK : LZF_E_HIP; }
-    template <class T> T* as() const { return static_cast<T*>(p); }
-};
+using lzf_host::Seg;
+using lzf_host::Staging;
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
-#define HIPOK(e) do { if ((e) != hipSuccess) return LZF_E_HIP; } while (0)
+// (on failure: nothing asynchronous may still be reading the host arrays of the frame that returns)
+#define HIPOK(e) do { if ((e) != hipSuccess) { (void)hipDeviceSynchronize(); return LZF_E_HIP; } } while (0)
+#define RCOK(e) do { const int rc__ = (e); if (rc__ != LZF_OK) { (void)hipDeviceSynchronize(); return rc__; } } while (0)
+constexpr size_t kDeviceHashMax = 32u << 20;
+#ifdef LZF_ANALYSIS      // LZF_FRAME_TRACE=1: wall-clock milliseconds between the marks of a *_many call, on stderr
+struct Trace {
+    bool on; std::chrono::steady_clock::time_point t0;
+    Trace() : on(getenv("LZF_FRAME_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) { if (!on) return; const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "[frame] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count()); t0 = t; }
+};
+#define TRACE_BEGIN() Trace trace__
+#define TRACE(what) trace__.mark(what)
+#else
+#define TRACE_BEGIN() do {} while (0)
+#define TRACE(what) do {} while (0)
+#endif
+
+// device scratch slots of the frame drivers (Staging::device)
+enum { S_IN = 0, S_OUT, S_PACK, S_JOBS, S_RES, S_LISTS, S_TABS, S_TABPTR, S_ADDS, S_TMPL, S_DICT, S_STEPS, S_STATE, S_HASH };
+
+lzf_frame_stats g_stats = {};
+
+// n small host arrays -> one device slot, one copy: ptr(i) is array i on the device
+struct Lists {
+    std::vector<uint8_t> h; std::vector<size_t> off; uint8_t* d = nullptr;
+    size_t add(const void* p, size_t bytes) { const size_t o = h.size(); h.resize(up256(o + bytes)); if (bytes && p) memcpy(h.data() + o, p, bytes); off.push_back(o); return off.size() - 1; }
+    int upload(Staging& sg, int slot, hipStream_t st) {
+        d = static_cast<uint8_t*>(sg.device(slot, h.size()));
+        if (!d) return LZF_E_HIP;
+        if (!h.empty()) HIPOK(hipMemcpyAsync(d, h.data(), h.size(), hipMemcpyHostToDevice, st));
+        return LZF_OK;
+    }
+    template <class T> T* ptr(size_t i) const { return reinterpret_cast<T*>(d + off[i]); }
+};
+
+// XXH32 of n host buffers on the worker threads (frames too long for one device chain each)
+void host_hashes(Staging& sg, const std::vector<const uint8_t*>& p, const std::vector<size_t>& n, std::vector<uint32_t>& out) {
+    out.resize(p.size());
+    sg.parallel_for(p.size(), [&](size_t i) { out[i] = lzf_xxh32(p[i], n[i], 0); });
+    g_stats.host_content_hashes += p.size();
+}
 }  // namespace
 extern "C" {
+
+void lzf_frame_get_stats(lzf_frame_stats* st) {
+    Staging& sg = Staging::get();
+    std::lock_guard<std::mutex> g(sg.lock());
+    *st = g_stats;
+    st->host_block_hashes = g_host_block_hashes;
+    st->device_block_hashes += g_reader_device_hashes;
+    st->h2d_copies = sg.counters.h2d_copies; st->d2h_copies = sg.counters.d2h_copies;
+    st->h2d_bytes = sg.counters.h2d_bytes; st->d2h_bytes = sg.counters.d2h_bytes;
+    st->pinned_bytes = sg.pinned_capacity();
+}
+void lzf_frame_release_scratch(void) {
+    Staging& sg = Staging::get();
+    std::lock_guard<std::mutex> g(sg.lock());
+    sg.release();
+}
+void lzf_frame_set_host_threads(uint32_t n) {
+    Staging& sg = Staging::get();
+    std::lock_guard<std::mutex> g(sg.lock());
+    sg.set_threads(n);
+}
 
 int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint8_t* const* in, const size_t* in_len,
                             uint8_t* const* out, const size_t* out_cap, size_t* out_len, int* status) {
@@ -266,53 +462,76 @@ int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint
     const size_t dict_len = dict ? (size_t)s->dictionary_len : 0;
     const bool indep = s->independent_blocks != 0;
     const bool per_block_prefix = indep && dict_len > 0;                       // :218,:268 in_buffer = dict ++ block, for every block
+    const bool bsum = s->block_checksums != 0, csum = s->content_checksum != 0;
 
-    // ---- layout: input slab (host staging -> one copy), output slab (cap n per block, :242), job list ordered by step
-    struct Fr { size_t nb, in_off, job0; };
+    // ---- layout: input slab, output slab (cap n per block, :242), job list ordered by step
+    struct Fr { size_t nb, in_off, job0, data_off; };                          // data_off: the frame's own bytes in the slab (not per_block_prefix)
     std::vector<Fr> fr(n_frames);
-    size_t in_total = 0, out_total = 0, n_jobs = 0, max_nb = 0;
+    size_t in_total = 0, out_total = 0, n_jobs = 0, max_nb = 0, pack_bound = 0;
     for (uint32_t f = 0; f < n_frames; ++f) {
         fr[f].nb = status[f] == LZF_OK ? (in_len[f] + bs - 1) / bs : 0;
-        fr[f].in_off = in_total;
+        fr[f].in_off = in_total; fr[f].data_off = in_total + (per_block_prefix ? 0 : dict_len);
         if (fr[f].nb) in_total = up256(in_total + (per_block_prefix ? fr[f].nb * dict_len : dict_len) + in_len[f]);
+        if (fr[f].nb) pack_bound = up256(pack_bound + in_len[f]);
         n_jobs += fr[f].nb; if (fr[f].nb > max_nb) max_nb = fr[f].nb;
     }
-    std::vector<lzf_compress_job> jobs(n_jobs ? n_jobs : 1);
+    if (n_jobs == 0) {                                                          // only empty inputs: header + EndMark each
+        for (uint32_t f = 0; f < n_frames; ++f) if (status[f] == LZF_OK) {
+            uint32_t content = 0; if (csum) content = lzf_xxh32(in[f], 0, 0);
+            status[f] = lzf_frame_assemble(s, 0, nullptr, nullptr, nullptr, content, out[f], out_cap[f], &out_len[f]);
+        }
+        return LZF_OK;
+    }
+    if (n_jobs > 0x7FFFFFFFull) return LZF_E_INVALID;
+    Staging& sg = Staging::get();
+    std::lock_guard<std::mutex> guard(sg.lock());
+    TRACE_BEGIN();
+    hipStream_t cs = sg.stream(0), hs = sg.stream(1);
+    if (!cs || !hs) return LZF_E_HIP;
+    if (!sg.pinned(in_total > pack_bound ? in_total : pack_bound)) return LZF_E_HIP;
+    TRACE("c: pinned slab");
+    std::vector<lzf_compress_job> jobs(n_jobs);
     std::vector<uint32_t> job_frame(n_jobs), job_block(n_jobs);
     std::vector<size_t> job_out_off(n_jobs);
     std::vector<size_t> step_off;                                               // linked: jobs of step k are [step_off[k], step_off[k+1])
-    std::vector<uint8_t> h_in(in_total ? in_total : 1);
-    DBuf d_in, d_out, d_jobs, d_res, d_tabs, d_tabptr, d_adds, d_tmpl;
-    int rc = d_in.alloc(in_total);
-    if (rc != LZF_OK) return rc;
-    uint8_t* const din = d_in.as<uint8_t>();
+    uint8_t* const din = static_cast<uint8_t*>(sg.device(S_IN, in_total));
+    if (!din) return LZF_E_HIP;
+    std::vector<Seg> up;                                                        // host -> slab
+    auto seg = [&](size_t off, const uint8_t* p, size_t n) { if (n) up.push_back({off, const_cast<uint8_t*>(p), n}); };
 
     lzf_u32_table tmpl;
-    if (dict_len >= 8) { rc = seeded_template(dict, dict_len, &tmpl); if (rc != LZF_OK) return rc; } else memset(&tmpl, 0, sizeof tmpl);
-    std::vector<void*> h_tabptr(n_jobs ? n_jobs : 1, nullptr);
-    std::vector<uint64_t> h_adds(n_jobs ? n_jobs : 1, 0);
+    if (dict_len >= 8) { RCOK(seeded_template(dict, dict_len, &tmpl)); } else memset(&tmpl, 0, sizeof tmpl);
+    std::vector<void*> h_tabptr(n_jobs, nullptr);
+    std::vector<uint64_t> h_adds(n_jobs, 0);
     uint32_t n_linked = 0;
     std::vector<uint32_t> lf_index(n_frames, 0);
-    if (!indep) for (uint32_t f = 0; f < n_frames; ++f) if (fr[f].nb) lf_index[f] = n_linked++;
-    if (!indep) { rc = d_tabs.alloc(sizeof(lzf_u32_table) * (size_t)(n_linked ? n_linked : 1)); if (rc != LZF_OK) return rc; }
-    else if (dict_len >= 8) { rc = d_tmpl.alloc(sizeof tmpl); if (rc != LZF_OK) return rc; HIPOK(hipMemcpy(d_tmpl.p, &tmpl, sizeof tmpl, hipMemcpyHostToDevice)); }
+    lzf_u32_table* d_tabs = nullptr; void* d_tmpl = nullptr;
+    if (!indep) {
+        for (uint32_t f = 0; f < n_frames; ++f) if (fr[f].nb) lf_index[f] = n_linked++;
+        d_tabs = static_cast<lzf_u32_table*>(sg.device(S_TABS, sizeof(lzf_u32_table) * (size_t)(n_linked ? n_linked : 1)));
+        if (!d_tabs) return LZF_E_HIP;
+    } else if (dict_len >= 8) {
+        d_tmpl = sg.device(S_TMPL, sizeof tmpl);
+        if (!d_tmpl) return LZF_E_HIP;
+        HIPOK(hipMemcpyAsync(d_tmpl, &tmpl, sizeof tmpl, hipMemcpyHostToDevice, cs));
+    }
 
     size_t jn = 0;
     if (indep) {
         for (uint32_t f = 0; f < n_frames; ++f) {
             fr[f].job0 = jn;
             size_t w = fr[f].in_off;
-            if (fr[f].nb && !per_block_prefix) { memcpy(h_in.data() + w, in[f], in_len[f]); }
+            if (fr[f].nb && !per_block_prefix) seg(w, in[f], in_len[f]);
             for (size_t i = 0; i < fr[f].nb; ++i, ++jn) {
                 const size_t off = i * bs, n = in_len[f] - off < bs ? in_len[f] - off : bs;
                 lzf_compress_job& j = jobs[jn];
                 memset(&j, 0, sizeof j);
                 if (per_block_prefix) {
-                    memcpy(h_in.data() + w, dict, dict_len); memcpy(h_in.data() + w + dict_len, in[f] + off, n);
+                    seg(w, dict, dict_len); seg(w + dict_len, in[f] + off, n);
                     j.input = din + w; j.input_len = dict_len + n; j.cursor = dict_len; w += dict_len + n;
                 } else { j.input = din + fr[f].in_off + off; j.input_len = n; j.cursor = 0; }
                 j.out_cap = n; j.table_kind = LZF_TABLE_U32;                   // :242, :202
-                if (dict_len >= 8) { j.table = d_tmpl.p; j.flags = LZF_CJOB_TABLE_READONLY; }     // :220,:270 template.clone()
+                if (dict_len >= 8) { j.table = d_tmpl; j.flags = LZF_CJOB_TABLE_READONLY; }       // :220,:270 template.clone()
                 job_frame[jn] = f; job_block[jn] = (uint32_t)i; job_out_off[jn] = out_total; out_total += n;
             }
         }
@@ -322,10 +541,7 @@ int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint
         // stream's slab; the table's offset grows by what the window forgets
         struct Ls { size_t lo, len; };                                          // in_buffer = slab[lo, lo + len)
         std::vector<Ls> ls(n_frames, Ls{0, dict_len});
-        for (uint32_t f = 0; f < n_frames; ++f) if (fr[f].nb) {
-            if (dict_len) memcpy(h_in.data() + fr[f].in_off, dict, dict_len);
-            memcpy(h_in.data() + fr[f].in_off + dict_len, in[f], in_len[f]);
-        }
+        for (uint32_t f = 0; f < n_frames; ++f) if (fr[f].nb) { seg(fr[f].in_off, dict, dict_len); seg(fr[f].in_off + dict_len, in[f], in_len[f]); }
         std::vector<uint64_t> pending_add(n_frames, 0);
         for (size_t k = 0; k < max_nb; ++k) {
             step_off.push_back(jn);
@@ -336,7 +552,7 @@ int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint
                 memset(&j, 0, sizeof j);
                 j.input = din + fr[f].in_off + ls[f].lo; j.input_len = ls[f].len + n; j.cursor = ls[f].len;   // :222,:243
                 j.out_cap = n; j.table_kind = LZF_TABLE_U32;
-                j.table = d_tabs.as<lzf_u32_table>() + lf_index[f];
+                j.table = d_tabs + lf_index[f];
                 h_tabptr[jn] = j.table; h_adds[jn] = pending_add[f];           // applied before this step
                 job_frame[jn] = f; job_block[jn] = (uint32_t)k; job_out_off[jn] = out_total; out_total += n;
                 ++jn;
@@ -347,189 +563,406 @@ int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint
         }
         step_off.push_back(jn);
     }
-    if (n_jobs == 0) {                                                          // only empty inputs: header + EndMark each
-        for (uint32_t f = 0; f < n_frames; ++f) if (status[f] == LZF_OK) {
-            uint32_t content = 0; if (s->content_checksum) content = lzf_xxh32(in[f], 0, 0);
-            status[f] = lzf_frame_assemble(s, 0, nullptr, nullptr, nullptr, content, out[f], out_cap[f], &out_len[f]);
-        }
-        return LZF_OK;
-    }
-    rc = d_out.alloc(out_total); if (rc != LZF_OK) return rc;
-    for (size_t q = 0; q < n_jobs; ++q) jobs[q].out = d_out.as<uint8_t>() + job_out_off[q];
-    rc = d_jobs.alloc(sizeof(lzf_compress_job) * n_jobs); if (rc != LZF_OK) return rc;
-    rc = d_res.alloc(sizeof(lzf_job_result) * n_jobs); if (rc != LZF_OK) return rc;
-    HIPOK(hipMemcpy(d_in.p, h_in.data(), in_total, hipMemcpyHostToDevice));
-    HIPOK(hipMemcpy(d_jobs.p, jobs.data(), sizeof(lzf_compress_job) * n_jobs, hipMemcpyHostToDevice));
+    uint8_t* const dout = static_cast<uint8_t*>(sg.device(S_OUT, out_total));
+    lzf_compress_job* const d_jobs = static_cast<lzf_compress_job*>(sg.device(S_JOBS, sizeof(lzf_compress_job) * n_jobs));
+    lzf_job_result* const d_res = static_cast<lzf_job_result*>(sg.device(S_RES, sizeof(lzf_job_result) * n_jobs));
+    if (!dout || !d_jobs || !d_res) return LZF_E_HIP;
+    for (size_t q = 0; q < n_jobs; ++q) jobs[q].out = dout + job_out_off[q];
+    // ---- inputs up (pieces, asynchronous), small arrays behind them
+    TRACE("c: layout + scratch");
+    HIPOK(sg.upload(up, in_total, din));
+    TRACE("c: upload issued");
+    HIPOK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(lzf_compress_job) * n_jobs, hipMemcpyHostToDevice, cs));
+    void** d_tabptr = nullptr; uint64_t* d_adds = nullptr;
+    std::vector<lzf_u32_table> h_tabs;
     if (!indep) {
-        std::vector<lzf_u32_table> h_tabs(n_linked, tmpl);                      // :213-214 table = template.clone()
-        HIPOK(hipMemcpy(d_tabs.p, h_tabs.data(), sizeof(lzf_u32_table) * n_linked, hipMemcpyHostToDevice));
-        rc = d_tabptr.alloc(sizeof(void*) * n_jobs); if (rc != LZF_OK) return rc;
-        rc = d_adds.alloc(sizeof(uint64_t) * n_jobs); if (rc != LZF_OK) return rc;
-        HIPOK(hipMemcpy(d_tabptr.p, h_tabptr.data(), sizeof(void*) * n_jobs, hipMemcpyHostToDevice));
-        HIPOK(hipMemcpy(d_adds.p, h_adds.data(), sizeof(uint64_t) * n_jobs, hipMemcpyHostToDevice));
+        h_tabs.assign(n_linked, tmpl);                                          // :213-214 table = template.clone()
+        HIPOK(hipMemcpyAsync(d_tabs, h_tabs.data(), sizeof(lzf_u32_table) * n_linked, hipMemcpyHostToDevice, cs));
+        d_tabptr = static_cast<void**>(sg.device(S_TABPTR, sizeof(void*) * n_jobs));
+        d_adds = static_cast<uint64_t*>(sg.device(S_ADDS, sizeof(uint64_t) * n_jobs));
+        if (!d_tabptr || !d_adds) return LZF_E_HIP;
+        HIPOK(hipMemcpyAsync(d_tabptr, h_tabptr.data(), sizeof(void*) * n_jobs, hipMemcpyHostToDevice, cs));
+        HIPOK(hipMemcpyAsync(d_adds, h_adds.data(), sizeof(uint64_t) * n_jobs, hipMemcpyHostToDevice, cs));
     }
+    HIPOK(sg.join_copies(cs));
     // ---- launches: no host round trip between the steps
     for (size_t k = 0; k + 1 < step_off.size(); ++k) {
         const size_t a = step_off[k], cnt = step_off[k + 1] - a;
         if (!cnt) continue;
-        if (!indep && k > 0) { rc = lzf_table_offset_batch(d_tabptr.as<void*>() + a, d_adds.as<uint64_t>() + a, (uint32_t)cnt, LZF_TABLE_U32, nullptr); if (rc != LZF_OK) return rc; }
-        rc = lzf_compress_batch(d_jobs.as<lzf_compress_job>() + a, d_res.as<lzf_job_result>() + a, (uint32_t)cnt, LZF_KINDS_U32, nullptr);
-        if (rc != LZF_OK) return rc;
+        if (!indep && k > 0) RCOK(lzf_table_offset_batch(d_tabptr + a, d_adds + a, (uint32_t)cnt, LZF_TABLE_U32, cs));
+        RCOK(lzf_compress_batch(d_jobs + a, d_res + a, (uint32_t)cnt, indep ? (LZF_KINDS_U32 | LZF_KINDS_U32_FRESH_ONLY) : LZF_KINDS_U32, cs));
     }
-    HIPOK(hipDeviceSynchronize());
-    std::vector<lzf_job_result> res(n_jobs);
-    std::vector<uint8_t> h_out(out_total ? out_total : 1);
-    HIPOK(hipMemcpy(res.data(), d_res.p, sizeof(lzf_job_result) * n_jobs, hipMemcpyDeviceToHost));
-    HIPOK(hipMemcpy(h_out.data(), d_out.p, out_total, hipMemcpyDeviceToHost));
-    // ---- assemble every frame (:244-263, :277-281)
+    // results come back through the pinned mailbox: [block results | content hashes | block checksums]
+    const size_t mb_res = 0, mb_chash = up256(sizeof(lzf_job_result) * n_jobs), mb_sums = mb_chash + up256(sizeof(uint32_t) * n_frames);
+    uint8_t* const mbox = sg.mailbox(mb_sums + sizeof(uint32_t) * n_jobs);
+    if (!mbox) return LZF_E_HIP;
+    const lzf_job_result* const res = reinterpret_cast<const lzf_job_result*>(mbox + mb_res);
+    HIPOK(hipMemcpyAsync(mbox + mb_res, d_res, sizeof(lzf_job_result) * n_jobs, hipMemcpyDeviceToHost, cs));
+    // ---- content checksums (:233-235): one device chain per frame on the second stream while the blocks compress;
+    //      long frames (and dict ++ block layouts, where the frame is not contiguous in the slab) on the workers
+    std::vector<uint32_t> content(n_frames, 0);
+    std::vector<uint32_t> dev_hash_frames, host_hash_frames;
+    if (csum) for (uint32_t f = 0; f < n_frames; ++f) if (status[f] == LZF_OK) {
+        if (fr[f].nb == 0) content[f] = lzf_xxh32(in[f], 0, 0);
+        else if (!per_block_prefix && in_len[f] <= kDeviceHashMax) dev_hash_frames.push_back(f);
+        else host_hash_frames.push_back(f);
+    }
+    Lists hl; uint32_t* d_chash = nullptr;
+    const uint32_t* const chash = reinterpret_cast<const uint32_t*>(mbox + mb_chash);
+    if (!dev_hash_frames.empty()) {
+        std::vector<const uint8_t*> p; std::vector<uint64_t> n;
+        for (uint32_t f : dev_hash_frames) { p.push_back(din + fr[f].data_off); n.push_back(in_len[f]); }
+        const size_t ip = hl.add(p.data(), p.size() * sizeof p[0]), il = hl.add(n.data(), n.size() * sizeof n[0]), io = hl.add(nullptr, p.size() * sizeof(uint32_t));
+        HIPOK(sg.join_copies(hs));
+        RCOK(hl.upload(sg, S_HASH, hs));
+        d_chash = hl.ptr<uint32_t>(io);
+        RCOK(lzf_xxh32_batch(hl.ptr<const uint8_t*>(ip), hl.ptr<uint64_t>(il), d_chash, (uint32_t)p.size(), hs));
+        HIPOK(hipMemcpyAsync(mbox + mb_chash, d_chash, p.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
+        g_stats.device_content_hashes += p.size();
+    }
+    if (!host_hash_frames.empty()) {
+        std::vector<const uint8_t*> p; std::vector<size_t> n; std::vector<uint32_t> h;
+        for (uint32_t f : host_hash_frames) { p.push_back(in[f]); n.push_back(in_len[f]); }
+        host_hashes(sg, p, n, h);
+        for (size_t i = 0; i < h.size(); ++i) content[host_hash_frames[i]] = h[i];
+    }
+    TRACE("c: launches + host hashes");
+    HIPOK(hipStreamSynchronize(cs));                                            // block results are here
+    TRACE("c: kernels done");
+    // ---- frame layout (:244-263, :277-281): header and length words straight into the caller's buffer, payloads packed
+    //      on the device in frame order (stored blocks, :250-255, from the input slab), checksums over the packed payloads
     std::vector<std::vector<size_t>> frame_jobs(n_frames);
     for (size_t q = 0; q < n_jobs; ++q) { auto& v = frame_jobs[job_frame[q]]; if (v.size() <= job_block[q]) v.resize(job_block[q] + 1); v[job_block[q]] = q; }
+    std::vector<const uint8_t*> r_src; std::vector<uint8_t*> r_dst; std::vector<uint64_t> r_len;      // device copies
+    std::vector<Seg> down;                                                      // packed slab -> caller
+    struct Patch { uint8_t* at; size_t hash_index; };
+    std::vector<Patch> sum_at;                                                  // where block checksum i goes
+    std::vector<uint8_t*> content_at(n_frames, nullptr);
+    size_t pk_total = 0; uint64_t r_max = 0;
+    std::vector<size_t> pk_pos;                                                 // packed offset of each range (r_dst is filled in once the slab exists)
     for (uint32_t f = 0; f < n_frames; ++f) {
         if (status[f] != LZF_OK) continue;
+        if (fr[f].nb == 0) { status[f] = lzf_frame_assemble(s, 0, nullptr, nullptr, nullptr, content[f], out[f], out_cap[f], &out_len[f]); continue; }   // an empty input: header + EndMark
         const size_t nb = fr[f].nb;
-        std::vector<const uint8_t*> payload(nb ? nb : 1);
-        std::vector<uint32_t> clen(nb ? nb : 1), rlen(nb ? nb : 1);
         int st = LZF_OK;
-        for (size_t i = 0; i < nb && st == LZF_OK; ++i) {
-            const size_t q = frame_jobs[f][i], off = i * bs, n = in_len[f] - off < bs ? in_len[f] - off : bs;
-            rlen[i] = (uint32_t)n;
-            if (res[q].status == LZF_OK) { clen[i] = (uint32_t)res[q].out_len; payload[i] = h_out.data() + job_out_off[q]; }
-            else if (res[q].status == LZF_OUTPUT_FULL) { clen[i] = UINT32_MAX; payload[i] = in[f] + off; }   // :250-255
-            else st = res[q].status;
-        }
+        for (size_t i = 0; i < nb && st == LZF_OK; ++i) { const int bst = res[frame_jobs[f][i]].status; if (bst != LZF_OK && bst != LZF_OUTPUT_FULL) st = bst; }
         if (st != LZF_OK) { status[f] = st; continue; }
-        uint32_t content = 0;
-        if (s->content_checksum) content = lzf_xxh32(in[f], in_len[f], 0);    // :233-235
-        status[f] = lzf_frame_assemble(s, (uint32_t)nb, payload.data(), clen.data(), rlen.data(), content, out[f], out_cap[f], &out_len[f]);
+        size_t w = write_header(s, bd, out[f]);
+        for (size_t i = 0; i < nb; ++i) {
+            const size_t q = frame_jobs[f][i], off = i * bs, n = in_len[f] - off < bs ? in_len[f] - off : bs;
+            const bool stored = res[q].status == LZF_OUTPUT_FULL;                                     // :250-255
+            const uint32_t len = stored ? (uint32_t)n : (uint32_t)res[q].out_len;
+            wr32(out[f] + w, stored ? (len | INCOMPRESSIBLE) : len); w += 4;                           // :247,253
+            r_src.push_back(stored ? jobs[q].input + jobs[q].cursor : jobs[q].out); r_len.push_back(len); pk_pos.push_back(pk_total);
+            if (len > r_max) r_max = len;
+            down.push_back({pk_total, out[f] + w, len});                                              // :258
+            pk_total += len; w += len;
+            if (bsum) { sum_at.push_back({out[f] + w, r_src.size() - 1}); w += 4; }                   // :259-263
+        }
+        pk_total = up256(pk_total);
+        wr32(out[f] + w, 0); w += 4;                                                                   // :277 EndMark
+        if (csum) { content_at[f] = out[f] + w; w += 4; }                                              // :279-281
+        out_len[f] = w;
     }
+    const uint32_t* const sums = reinterpret_cast<const uint32_t*>(mbox + mb_sums);
+    if (!r_src.empty()) {
+        uint8_t* const dpack = static_cast<uint8_t*>(sg.device(S_PACK, pk_total));
+        if (!dpack) return LZF_E_HIP;
+        r_dst.resize(r_src.size());
+        for (size_t i = 0; i < r_src.size(); ++i) r_dst[i] = dpack + pk_pos[i];
+        Lists rl;
+        const size_t is = rl.add(r_src.data(), r_src.size() * sizeof r_src[0]), id = rl.add(r_dst.data(), r_dst.size() * sizeof r_dst[0]),
+                     il = rl.add(r_len.data(), r_len.size() * sizeof r_len[0]), io = rl.add(nullptr, r_src.size() * sizeof(uint32_t));
+        RCOK(rl.upload(sg, S_LISTS, cs));
+        RCOK(lzf_copy_ranges(rl.ptr<const uint8_t*>(is), rl.ptr<uint8_t*>(id), rl.ptr<uint64_t>(il), (uint32_t)r_src.size(), r_max, cs));
+        if (bsum) {
+            RCOK(lzf_xxh32_batch(rl.ptr<const uint8_t*>(id), rl.ptr<uint64_t>(il), rl.ptr<uint32_t>(io), (uint32_t)r_src.size(), cs));
+            g_stats.device_block_hashes += r_src.size();
+        }
+        TRACE("c: frame layout + pack issued");
+        if (bsum) HIPOK(hipMemcpyAsync(mbox + mb_sums, rl.ptr<uint32_t>(io), r_src.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
+        HIPOK(sg.download(down, pk_total, dpack, cs));                          // (returns when the payloads are in place)
+        TRACE("c: download");
+        if (bsum) {
+            HIPOK(hipStreamSynchronize(cs));
+            for (const Patch& pt : sum_at) wr32(pt.at, sums[pt.hash_index]);
+        }
+    }
+    HIPOK(hipStreamSynchronize(hs));
+    TRACE("c: content hashes");
+    for (size_t i = 0; i < dev_hash_frames.size(); ++i) content[dev_hash_frames[i]] = chash[i];
+    for (uint32_t f = 0; f < n_frames; ++f) if (content_at[f]) wr32(content_at[f], content[f]);
+    ++g_stats.calls;
     return LZF_OK;
 }
 
+}  // extern "C"
+namespace {
 
-int lzf_frame_decompress_many(uint32_t n_frames, const uint8_t* const* in, const size_t* in_len, const uint8_t* dict, size_t dict_len,
-                              uint8_t* const* out, const size_t* out_cap, size_t* out_len, size_t* consumed, int* status) {
-    if (n_frames && (!in || !in_len || !out || !out_cap || !out_len || !status)) return LZF_E_INVALID;
-    if (!dict) dict_len = 0;
-    struct Fr {
-        lzf_frame_info fi; std::vector<Blk> blocks; FrameScan sc; bool live = false, linked = false;
-        size_t in_off = 0, out_off = 0, out_size = 0;      // device offsets: the frame's bytes; linked: the stream's output buffer
-        std::vector<size_t> job;                             // per block: job index or SIZE_MAX (stored)
-        std::vector<size_t> slot;                            // independent: device offset of the block's output slot
-        uint32_t chain = 0;                                  // linked: index among the linked streams
-    };
-    std::vector<Fr> fr(n_frames);
-    size_t in_total = 0, out_total = 0, n_jobs = 0, max_steps = 0;
+struct DFrame {
+    lzf_frame_info fi; std::vector<Blk> blocks; FrameScan sc; bool live = false, linked = false;
+    size_t in_off = 0, out_off = 0, out_size = 0;      // device offsets: the frame's bytes; linked: the stream's output buffer
+    std::vector<size_t> job;                             // per block: job index or SIZE_MAX (stored)
+    std::vector<size_t> slot;                            // independent: device offset of the block's output slot
+    uint32_t chain = 0;                                  // linked: index among the linked streams
+    size_t need = 0;                                     // device bytes this frame asks for (input + output room + packed result)
+};
+// the most a block of `len` compressed bytes can decode to: every byte a 255-run length byte (raw/decompress.rs:40-56)
+inline size_t block_out_bound(size_t bmax, size_t len) { const size_t e = 255 * len + 16; return e < bmax ? e : bmax; }
+
+// One pass over frames [f0, f1): everything on the device at once.
+int decompress_group(Staging& sg, std::vector<DFrame>& fr, uint32_t f0, uint32_t f1, const uint8_t* const* in, const size_t* in_len,
+                     const uint8_t* dict, size_t dict_len, uint8_t* const* out, const size_t* out_cap, size_t* out_len, size_t* consumed, int* status) {
+    hipStream_t cs = sg.stream(0), hs = sg.stream(1);
+    if (!cs || !hs) return LZF_E_HIP;
+    TRACE_BEGIN();
+    size_t in_total = 0, out_total = 0, max_steps = 0, n_sums = 0, pack_bound = 0;
     uint32_t n_chain = 0;
-    for (uint32_t f = 0; f < n_frames; ++f) {
-        Fr& F = fr[f];
-        out_len[f] = 0; if (consumed) consumed[f] = 0;
-        const int rc = lzf_frame_read_header(in[f], in_len[f], &F.fi);
-        if (rc != LZF_OK) { status[f] = rc; if (consumed) consumed[f] = rc == LZF_F_INPUT_ERROR ? in_len[f] : 0; continue; }
-        status[f] = LZF_OK; F.live = true; F.linked = !(F.fi.flags & FL_INDEP);
-        scan_blocks(in[f], in_len[f], F.fi, F.blocks, F.sc);
-        if (consumed) consumed[f] = F.sc.consumed;
+    std::vector<Seg> up;
+    for (uint32_t f = f0; f < f1; ++f) {
+        DFrame& F = fr[f];
+        if (!F.live) continue;
         const size_t nb = F.blocks.size(), bmax = (size_t)F.fi.block_maxsize;
-        F.in_off = in_total; in_total = up256(in_total + in_len[f]);
+        F.in_off = in_total; in_total = up256(in_total + F.sc.consumed);
+        if (F.sc.consumed) up.push_back({F.in_off, const_cast<uint8_t*>(in[f]), F.sc.consumed});
         F.job.assign(nb, SIZE_MAX); F.slot.assign(nb, 0);
-        size_t sumbl = 0;
-        for (size_t i = 0; i < nb; ++i) if (F.blocks[i].compressed) { F.job[i] = 0; sumbl += F.blocks[i].len; }
+        if (F.fi.flags & FL_BLOCKSUM) n_sums += nb;
+        size_t bound = 0;
+        for (size_t i = 0; i < nb; ++i) bound += F.blocks[i].compressed ? block_out_bound(bmax, F.blocks[i].len) : F.blocks[i].len;
+        pack_bound = up256(pack_bound + bound);
         if (F.linked) {
             // a block may run past its limit by its literals before the stream is stopped: room for that
-            if (nb) { F.chain = n_chain++; F.out_off = out_total; F.out_size = nb * bmax + sumbl + 64; out_total = up256(out_total + F.out_size); if (nb > max_steps) max_steps = nb; }
+            if (nb) { F.chain = n_chain++; F.out_off = out_total; F.out_size = bound + F.sc.consumed + 64; out_total = up256(out_total + F.out_size); if (nb > max_steps) max_steps = nb; }
         } else {
-            for (size_t i = 0; i < nb; ++i) if (F.blocks[i].compressed) { F.slot[i] = out_total; out_total = up256(out_total + bmax + F.blocks[i].len); }   // limit + C
+            for (size_t i = 0; i < nb; ++i) if (F.blocks[i].compressed) { F.slot[i] = out_total; out_total = up256(out_total + block_out_bound(bmax, F.blocks[i].len) + F.blocks[i].len); }   // limit + C
         }
     }
+    if (!sg.pinned(in_total > pack_bound ? in_total : pack_bound)) return LZF_E_HIP;
+    uint8_t* const din = static_cast<uint8_t*>(sg.device(S_IN, in_total));
+    uint8_t* const dout = static_cast<uint8_t*>(sg.device(S_OUT, out_total));
+    uint8_t* d_dict = nullptr;
+    if (!din || !dout) return LZF_E_HIP;
+    if (dict_len) { d_dict = static_cast<uint8_t*>(sg.device(S_DICT, dict_len)); if (!d_dict) return LZF_E_HIP; HIPOK(hipMemcpyAsync(d_dict, dict, dict_len, hipMemcpyHostToDevice, cs)); }
     // ---- job list ordered by step: step 0 = every block of the independent frames + block 0 of the linked streams
     std::vector<lzf_decompress_job> jobs;
     std::vector<size_t> step_off;
-    DBuf d_in, d_out, d_dict, d_jobs, d_res, d_steps, d_state;
-    int rc = d_in.alloc(in_total); if (rc != LZF_OK) return rc;
-    rc = d_out.alloc(out_total); if (rc != LZF_OK) return rc;
-    if (dict_len) { rc = d_dict.alloc(dict_len); if (rc != LZF_OK) return rc; HIPOK(hipMemcpy(d_dict.p, dict, dict_len, hipMemcpyHostToDevice)); }
-    uint8_t* const din = d_in.as<uint8_t>(); uint8_t* const dout = d_out.as<uint8_t>();
     const size_t n_steps = max_steps > 1 ? max_steps : 1;
     std::vector<lzf_chain_step> csteps((size_t)n_chain * n_steps);
     for (size_t k = 0; k < n_steps; ++k) {
         step_off.push_back(jobs.size());
-        for (uint32_t f = 0; f < n_frames; ++f) {
-            Fr& F = fr[f];
+        for (uint32_t f = f0; f < f1; ++f) {
+            DFrame& F = fr[f];
             if (!F.live) continue;
             const size_t nb = F.blocks.size(), bmax = (size_t)F.fi.block_maxsize;
             auto add_job = [&](size_t i) {
                 lzf_decompress_job j;
                 memset(&j, 0, sizeof j);
                 j.input = din + F.in_off + (F.blocks[i].data - in[f]); j.input_len = F.blocks[i].len;
-                j.prefix = d_dict.as<uint8_t>(); j.prefix_len = dict_len;                       // :239-245
-                if (F.linked) { j.out = dout + F.out_off; j.out_cap = bmax + F.blocks[i].len; j.output_limit = bmax; }   // (patched per step)
-                else { j.out = dout + F.slot[i]; j.out_cap = bmax + F.blocks[i].len; j.output_limit = bmax; }           // :248
+                j.prefix = d_dict; j.prefix_len = dict_len;                                       // :239-245
+                const size_t lim = bmax;                                                          // :248
+                if (F.linked) { j.out = dout + F.out_off; j.out_cap = lim + F.blocks[i].len; j.output_limit = lim; }   // (patched per step)
+                else { j.out = dout + F.slot[i]; j.out_cap = block_out_bound(bmax, F.blocks[i].len) + F.blocks[i].len; j.output_limit = lim; }
                 F.job[i] = jobs.size(); jobs.push_back(j);
             };
             if (!F.linked) { if (k == 0) for (size_t i = 0; i < nb; ++i) if (F.blocks[i].compressed) add_job(i); continue; }
             if (!nb) continue;
-            lzf_chain_step& cs = csteps[k * n_chain + F.chain];
-            memset(&cs, 0, sizeof cs);
-            cs.prev_job = (k > 0 && k - 1 < nb && F.blocks[k - 1].compressed) ? (uint32_t)F.job[k - 1] : UINT32_MAX;
-            cs.job = UINT32_MAX; cs.out = dout + F.out_off; cs.block_maxsize = bmax;
+            lzf_chain_step& st = csteps[k * n_chain + F.chain];
+            memset(&st, 0, sizeof st);
+            st.prev_job = (k > 0 && k - 1 < nb && F.blocks[k - 1].compressed) ? (uint32_t)F.job[k - 1] : UINT32_MAX;
+            st.job = UINT32_MAX; st.out = dout + F.out_off; st.block_maxsize = bmax;
             if (k < nb) {
-                if (F.blocks[k].compressed) { add_job(k); cs.job = (uint32_t)F.job[k]; }
-                else { cs.stored_len = F.blocks[k].len; cs.stored_src = din + F.in_off + (F.blocks[k].data - in[f]); }
+                if (F.blocks[k].compressed) { add_job(k); st.job = (uint32_t)F.job[k]; }
+                else { st.stored_len = F.blocks[k].len; st.stored_src = din + F.in_off + (F.blocks[k].data - in[f]); }
             }
         }
     }
     step_off.push_back(jobs.size());
-    n_jobs = jobs.size();
-    std::vector<lzf_job_result> res(n_jobs ? n_jobs : 1);
-    if (in_total) for (uint32_t f = 0; f < n_frames; ++f) if (fr[f].live && in_len[f]) HIPOK(hipMemcpy(din + fr[f].in_off, in[f], in_len[f], hipMemcpyHostToDevice));
-    if (n_jobs || n_chain) {
-        rc = d_jobs.alloc(sizeof(lzf_decompress_job) * n_jobs); if (rc != LZF_OK) return rc;
-        rc = d_res.alloc(sizeof(lzf_job_result) * n_jobs); if (rc != LZF_OK) return rc;
-        if (n_jobs) HIPOK(hipMemcpy(d_jobs.p, jobs.data(), sizeof(lzf_decompress_job) * n_jobs, hipMemcpyHostToDevice));
-        if (n_chain) {
-            rc = d_steps.alloc(sizeof(lzf_chain_step) * csteps.size()); if (rc != LZF_OK) return rc;
-            rc = d_state.alloc(sizeof(lzf_chain_state) * n_chain); if (rc != LZF_OK) return rc;
-            HIPOK(hipMemcpy(d_steps.p, csteps.data(), sizeof(lzf_chain_step) * csteps.size(), hipMemcpyHostToDevice));
-            HIPOK(hipMemset(d_state.p, 0, sizeof(lzf_chain_state) * n_chain));
-        }
-        for (size_t k = 0; k < n_steps; ++k) {
-            if (n_chain) { rc = lzf_chain_decompress_step(d_steps.as<lzf_chain_step>() + k * n_chain, d_state.as<lzf_chain_state>(), n_chain, d_jobs.as<lzf_decompress_job>(), d_res.as<lzf_job_result>(), nullptr); if (rc != LZF_OK) return rc; }
-            const size_t a = step_off[k], cnt = step_off[k + 1] - a;
-            if (cnt) { rc = lzf_decompress_batch(d_jobs.as<lzf_decompress_job>() + a, d_res.as<lzf_job_result>() + a, (uint32_t)cnt, nullptr); if (rc != LZF_OK) return rc; }
-        }
-        HIPOK(hipDeviceSynchronize());
-        if (n_jobs) HIPOK(hipMemcpy(res.data(), d_res.p, sizeof(lzf_job_result) * n_jobs, hipMemcpyDeviceToHost));
+    const size_t n_jobs = jobs.size();
+    if (n_jobs > 0x7FFFFFFFull) return LZF_E_INVALID;
+    // results come back through the pinned mailbox: [block results | block checksums | content hashes]
+    const size_t mb_sums = up256(sizeof(lzf_job_result) * n_jobs), mb_chash = mb_sums + up256(sizeof(uint32_t) * n_sums);
+    uint8_t* const mbox = sg.mailbox(mb_chash + sizeof(uint32_t) * (f1 - f0));
+    if (!mbox) return LZF_E_HIP;
+    const lzf_job_result* const res = reinterpret_cast<const lzf_job_result*>(mbox);
+    const uint32_t* const sums = reinterpret_cast<const uint32_t*>(mbox + mb_sums);
+    const uint32_t* const chash = reinterpret_cast<const uint32_t*>(mbox + mb_chash);
+    TRACE("d: layout + scratch");
+    HIPOK(sg.upload(up, in_total, din));
+    TRACE("d: upload issued");
+    // ---- block checksums (:228-235): every block of every frame that carries them, one launch on the second stream
+    Lists bl;
+    if (n_sums) {
+        std::vector<const uint8_t*> p; std::vector<uint64_t> n;
+        for (uint32_t f = f0; f < f1; ++f) if (fr[f].live && (fr[f].fi.flags & FL_BLOCKSUM))
+            for (const Blk& b : fr[f].blocks) { p.push_back(din + fr[f].in_off + (b.data - in[f])); n.push_back(b.len); }
+        const size_t ip = bl.add(p.data(), p.size() * sizeof p[0]), il = bl.add(n.data(), n.size() * sizeof n[0]), io = bl.add(nullptr, n_sums * sizeof(uint32_t));
+        HIPOK(sg.join_copies(hs));
+        RCOK(bl.upload(sg, S_HASH, hs));
+        RCOK(lzf_xxh32_batch(bl.ptr<const uint8_t*>(ip), bl.ptr<uint64_t>(il), bl.ptr<uint32_t>(io), (uint32_t)n_sums, hs));
+        HIPOK(hipMemcpyAsync(mbox + mb_sums, bl.ptr<uint32_t>(io), n_sums * sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
+        g_stats.device_block_hashes += n_sums;
     }
-    // ---- per frame: the delivery loop of lzf_frame_decompress, on the block lengths the device reports
-    for (uint32_t f = 0; f < n_frames; ++f) {
-        Fr& F = fr[f];
+    if (n_jobs || n_chain) {
+        lzf_decompress_job* const d_jobs = static_cast<lzf_decompress_job*>(sg.device(S_JOBS, sizeof(lzf_decompress_job) * n_jobs));
+        lzf_job_result* const d_res = static_cast<lzf_job_result*>(sg.device(S_RES, sizeof(lzf_job_result) * n_jobs));
+        if (!d_jobs || !d_res) return LZF_E_HIP;
+        if (n_jobs) HIPOK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(lzf_decompress_job) * n_jobs, hipMemcpyHostToDevice, cs));
+        lzf_chain_step* d_steps = nullptr; lzf_chain_state* d_state = nullptr;
+        if (n_chain) {
+            d_steps = static_cast<lzf_chain_step*>(sg.device(S_STEPS, sizeof(lzf_chain_step) * csteps.size()));
+            d_state = static_cast<lzf_chain_state*>(sg.device(S_STATE, sizeof(lzf_chain_state) * n_chain));
+            if (!d_steps || !d_state) return LZF_E_HIP;
+            HIPOK(hipMemcpyAsync(d_steps, csteps.data(), sizeof(lzf_chain_step) * csteps.size(), hipMemcpyHostToDevice, cs));
+            HIPOK(hipMemsetAsync(d_state, 0, sizeof(lzf_chain_state) * n_chain, cs));
+        }
+        HIPOK(sg.join_copies(cs));
+        for (size_t k = 0; k < n_steps; ++k) {
+            if (n_chain) RCOK(lzf_chain_decompress_step(d_steps + k * n_chain, d_state, n_chain, d_jobs, d_res, cs));
+            const size_t a = step_off[k], cnt = step_off[k + 1] - a;
+            if (cnt) RCOK(lzf_decompress_batch(d_jobs + a, d_res + a, (uint32_t)cnt, cs));
+        }
+        if (n_jobs) HIPOK(hipMemcpyAsync(mbox, d_res, sizeof(lzf_job_result) * n_jobs, hipMemcpyDeviceToHost, cs));
+    } else {
+        HIPOK(sg.join_copies(cs));
+    }
+    TRACE("d: launches");
+    HIPOK(hipStreamSynchronize(cs));
+    HIPOK(hipStreamSynchronize(hs));
+    TRACE("d: kernels done");
+    // ---- per frame: the delivery loop of the reader (decompress.rs:198-288), on the block lengths the device reports
+    std::vector<const uint8_t*> r_src; std::vector<uint64_t> r_len; std::vector<size_t> pk_pos;
+    std::vector<Seg> down;
+    struct Want { uint32_t f; size_t pk; size_t n; };
+    std::vector<Want> dev_hash, host_hash;
+    size_t pk_total = 0, sum_i = 0; uint64_t r_max = 0;
+    for (uint32_t f = f0; f < f1; ++f) {
+        DFrame& F = fr[f];
         if (!F.live) continue;
         const size_t nb = F.blocks.size(), bmax = (size_t)F.fi.block_maxsize;
-        const bool csum = F.fi.flags & FL_CSUM;
+        const bool csum = F.fi.flags & FL_CSUM, bsum = F.fi.flags & FL_BLOCKSUM;
+        const size_t sum0 = sum_i; if (bsum) sum_i += nb;
         size_t w = 0, hist = 0;        // bytes delivered; linked: length of the stream's device buffer so far
         int st = LZF_OK; bool stopped = false;
+        const size_t pk0 = pk_total;
+        auto range = [&](const uint8_t* src, size_t n) {
+            if (!n) return;
+            if (!r_src.empty() && r_src.back() + r_len.back() == src && pk_pos.back() + r_len.back() == pk0 + w) r_len.back() += n;   // (linked streams: one range)
+            else { r_src.push_back(src); r_len.push_back(n); pk_pos.push_back(pk0 + w); }
+            if (r_len.back() > r_max) r_max = r_len.back();
+        };
         for (size_t i = 0; i < nb; ++i) {
+            const Blk& b = F.blocks[i];
+            if (consumed) consumed[f] = b.end_off;                                             // what the reader has read when it stops in this block
+            if (bsum && sums[sum0 + i] != b.want_sum) { st = LZF_F_BLOCK_CHECKSUM_FAIL; break; }   // :228-235
             size_t n; const uint8_t* dsrc;                                                    // device address of the block's bytes
-            if (F.blocks[i].compressed) {
+            if (b.compressed) {
                 const lzf_job_result& r = res[F.job[i]];
                 if (r.status != LZF_OK) { st = r.status; break; }                             // CodecError
                 if (F.linked) { n = (size_t)r.out_len - hist; dsrc = dout + F.out_off + hist; }
                 else { n = (size_t)r.out_len; dsrc = dout + F.slot[i]; }
-            } else { n = F.blocks[i].len; dsrc = nullptr; }                                    // :250 stored: the bytes are in `in`
+            } else { n = b.len; dsrc = F.linked ? dout + F.out_off + hist : din + F.in_off + (b.data - in[f]); }   // :250 stored
             hist += n;
             if (n > bmax) { st = LZF_F_BLOCK_SIZE_OVERFLOW; break; }                          // :272-274
             if (out_cap[f] - w < n) { st = LZF_OUT_CAPACITY; break; }
-            if (n && dsrc) HIPOK(hipMemcpy(out[f] + w, dsrc, n, hipMemcpyDeviceToHost));
-            else if (n) memcpy(out[f] + w, F.blocks[i].data, n);
+            range(dsrc, n);
             w += n;
             if (n == 0) { stopped = true; break; }                                            // the io::Read adapter stops at an empty block (:52-71,:286)
         }
         out_len[f] = w;
+        if (w) down.push_back({pk0, out[f], w});
+        pk_total = up256(pk0 + w);
         if (st != LZF_OK) { status[f] = st; continue; }
         if (stopped) continue;
+        if (consumed) consumed[f] = F.sc.consumed;
         if (F.sc.err != LZF_OK) { status[f] = F.sc.err; continue; }
-        if (F.sc.endmark && csum && F.sc.want_content != lzf_xxh32(out[f], w, 0)) status[f] = LZF_F_FRAME_CHECKSUM_FAIL;   // :207-211
+        if (F.sc.endmark && csum) { (w <= kDeviceHashMax ? dev_hash : host_hash).push_back({f, pk0, w}); }   // :207-211
+    }
+    if (!r_src.empty() || !dev_hash.empty()) {
+        uint8_t* const dpack = static_cast<uint8_t*>(sg.device(S_PACK, pk_total));
+        if (!dpack) return LZF_E_HIP;
+        std::vector<uint8_t*> r_dst(r_src.size());
+        for (size_t i = 0; i < r_src.size(); ++i) r_dst[i] = dpack + pk_pos[i];
+        std::vector<const uint8_t*> hp; std::vector<uint64_t> hn;
+        for (const Want& h : dev_hash) { hp.push_back(dpack + h.pk); hn.push_back(h.n); }
+        Lists rl;
+        const size_t is = rl.add(r_src.data(), r_src.size() * sizeof(void*)), id = rl.add(r_dst.data(), r_dst.size() * sizeof(void*)), il = rl.add(r_len.data(), r_len.size() * sizeof(uint64_t));
+        const size_t ihp = rl.add(hp.data(), hp.size() * sizeof(void*)), ihn = rl.add(hn.data(), hn.size() * sizeof(uint64_t)), iho = rl.add(nullptr, hp.size() * sizeof(uint32_t));
+        RCOK(rl.upload(sg, S_LISTS, cs));
+        RCOK(lzf_copy_ranges(rl.ptr<const uint8_t*>(is), rl.ptr<uint8_t*>(id), rl.ptr<uint64_t>(il), (uint32_t)r_src.size(), r_max, cs));
+        if (!hp.empty()) {                                                                    // the content hash runs on the second stream while the output goes home
+            hipEvent_t packed = nullptr;
+            HIPOK(hipEventCreateWithFlags(&packed, hipEventDisableTiming));
+            HIPOK(hipEventRecord(packed, cs)); HIPOK(hipStreamWaitEvent(hs, packed, 0));
+            RCOK(lzf_xxh32_batch(rl.ptr<const uint8_t*>(ihp), rl.ptr<uint64_t>(ihn), rl.ptr<uint32_t>(iho), (uint32_t)hp.size(), hs));
+            HIPOK(hipMemcpyAsync(mbox + mb_chash, rl.ptr<uint32_t>(iho), hp.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
+            HIPOK(hipEventDestroy(packed));
+            g_stats.device_content_hashes += hp.size();
+        }
+        TRACE("d: delivery + pack issued");
+        HIPOK(sg.download(down, pk_total, dpack, cs));
+        TRACE("d: download");
+        HIPOK(hipStreamSynchronize(hs));
+        TRACE("d: content hashes");
+    }
+    for (size_t i = 0; i < dev_hash.size(); ++i) if (fr[dev_hash[i].f].sc.want_content != chash[i]) status[dev_hash[i].f] = LZF_F_FRAME_CHECKSUM_FAIL;
+    if (!host_hash.empty()) {
+        std::vector<const uint8_t*> p; std::vector<size_t> n; std::vector<uint32_t> h;
+        for (const Want& q : host_hash) { p.push_back(out[q.f]); n.push_back(q.n); }
+        host_hashes(sg, p, n, h);
+        for (size_t i = 0; i < h.size(); ++i) if (fr[host_hash[i].f].sc.want_content != h[i]) status[host_hash[i].f] = LZF_F_FRAME_CHECKSUM_FAIL;
     }
     return LZF_OK;
+}
+}  // namespace
+extern "C" {
+
+int lzf_frame_decompress_many(uint32_t n_frames, const uint8_t* const* in, const size_t* in_len, const uint8_t* dict, size_t dict_len,
+                              uint8_t* const* out, const size_t* out_cap, size_t* out_len, size_t* consumed, int* status) {
+    if (n_frames && (!in || !in_len || !out || !out_cap || !out_len || !status)) return LZF_E_INVALID;
+    if (!dict) dict_len = 0;
+    std::vector<DFrame> fr(n_frames);
+    for (uint32_t f = 0; f < n_frames; ++f) {
+        DFrame& F = fr[f];
+        out_len[f] = 0; if (consumed) consumed[f] = 0;
+        size_t hdr_read = 0;
+        const int rc = read_header_ex(in[f], in_len[f], &F.fi, &hdr_read);
+        if (rc != LZF_OK) { status[f] = rc; if (consumed) consumed[f] = hdr_read; continue; }
+        status[f] = LZF_OK; F.live = true; F.linked = !(F.fi.flags & FL_INDEP);
+        scan_blocks(in[f], in_len[f], F.fi, F.blocks, F.sc);
+        if (consumed) consumed[f] = F.sc.consumed;
+        // device memory the frame asks for: its bytes, an output slot per block bounded by what the block can expand to
+        // (a 5-byte block cannot claim block_maxsize), and the packed result
+        const size_t bmax = (size_t)F.fi.block_maxsize;
+        size_t bound = 0;
+        for (const Blk& b : F.blocks) bound += (b.compressed ? block_out_bound(bmax, b.len) : 0) + b.len + 256;
+        F.need = F.sc.consumed + 2 * bound + 4096;
+    }
+    if (n_frames == 0) return LZF_OK;
+    Staging& sg = Staging::get();
+    std::lock_guard<std::mutex> guard(sg.lock());
+    // ---- slices: as many frames per pass as the memory budget holds (half of what the device has free, and at most
+    //      kPinnedMax of pinned host memory per pass); a frame that does not fit alone reports LZF_E_NO_MEMORY
+    size_t free_b = 0, total_b = 0;
+    HIPOK(hipMemGetInfo(&free_b, &total_b));
+    size_t budget = g_budget ? g_budget : free_b / 2;
+    for (uint32_t f0 = 0; f0 < n_frames;) {
+        size_t sum = 0; uint32_t f1 = f0;
+        while (f1 < n_frames && (f1 == f0 || sum + fr[f1].need <= budget)) { sum += fr[f1].live ? fr[f1].need : 0; ++f1; }
+        if (f1 == f0 + 1 && fr[f0].live && fr[f0].need > budget) {
+            status[f0] = LZF_E_NO_MEMORY; out_len[f0] = 0; if (consumed) consumed[f0] = 0;
+            f0 = f1; continue;
+        }
+        RCOK(decompress_group(sg, fr, f0, f1, in, in_len, dict, dict_len, out, out_cap, out_len, consumed, status));
+        f0 = f1;
+    }
+    ++g_stats.calls;
+    return LZF_OK;
+}
+
+void lzf_frame_set_memory_budget(size_t bytes) {
+    Staging& sg = Staging::get();
+    std::lock_guard<std::mutex> g(sg.lock());
+    g_budget = bytes;
 }
 
 }  // extern "C"

@@ -1,23 +1,35 @@
 // kernels.h — declarations of the gfx950 kernels for the C-ABI translation unit.
+//
+// The product library (build.py, no defines) holds the kernels lzf_decompress_batch / lzf_compress_batch launch:
+// paired48, paired24, staged16, the two compress kernels and the small helpers.  -DLZF_ANALYSIS (liblzfear_hip_analysis.so)
+// adds every other kernel generation — kept for A/B timing and counter studies (tools/, profiles/) — and the environment
+// variables that select them; nothing below an `#ifdef LZF_ANALYSIS` is in the product.
 #pragma once
 #include "lzf_device.h"
 
 namespace lzf {
 // perm (optional, everywhere below): launch index -> job index; capi.hip launches large batches longest job first
+#ifdef LZF_ANALYSIS
 __global__ void lzf_decompress_wave_kernel(const lzf_decompress_job* __restrict__ jobs,
                                            lzf_job_result* __restrict__ results, uint32_t n_jobs, const uint32_t* __restrict__ perm);
+#endif
 template <int RING, int S, int TOKCAP, bool STAGE>
 __global__ void lzf_decompress_batched_kernel(const lzf_decompress_job* __restrict__ jobs,
                                               lzf_job_result* __restrict__ results, uint32_t n_jobs, const uint32_t* __restrict__ perm);
 // Tuning variants of the batched kernel: X(name, ring bytes, region bytes, token-list entries, chunk staged in LDS).
 // LZF_DECOMPRESS_KERNEL=<name> selects one (A/B knob; every variant implements the same contract).
+#ifdef LZF_ANALYSIS
 #define LZF_DECOMPRESS_VARIANTS(X) \
     X(staged16, 4096, 16, 256, true)    \
     X(staged32, 4096, 32, 512, true)    \
     X(direct4w, 4096, 256, 2048, false)
+#else
+#define LZF_DECOMPRESS_VARIANTS(X) X(staged16, 4096, 16, 256, true)
+#endif
 #define LZF_EXT(NAME, R, S_, T, ST) extern template __global__ void lzf_decompress_batched_kernel<R, S_, T, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*);
 LZF_DECOMPRESS_VARIANTS(LZF_EXT)
 #undef LZF_EXT
+#ifdef LZF_ANALYSIS
 // Third generation (lz4_decompress_windowed.hip): X(name, ring bytes, region bytes).  The token list of a chunk lives
 // in a scratch area of LZF_WINDOWED_STRIDE(region) u16 entries per job.
 template <int RING, int R, int WIN>
@@ -30,17 +42,25 @@ __global__ void lzf_decompress_windowed_kernel(const lzf_decompress_job* __restr
 #define LZF_EXTW(NAME, RG, R_, W_) extern template __global__ void lzf_decompress_windowed_kernel<RG, R_, W_>(const lzf_decompress_job*, lzf_job_result*, uint32_t, uint16_t*, uint32_t);
 LZF_WINDOWED_VARIANTS(LZF_EXTW)
 #undef LZF_EXTW
+#endif
 // Producer / consumer pairs (lz4_decompress_paired.hip): X(name, ring bytes, region bytes, token-list entries).
 template <int RING, int S, int TOKCAP>
 __global__ void lzf_decompress_paired_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
                                              const uint32_t* __restrict__ perm);
+#ifdef LZF_ANALYSIS
 #define LZF_PAIRED_VARIANTS(X) \
     X(paired16, 4096, 16, 256) \
     X(paired24, 4096, 24, 384) \
     X(paired48, 4096, 48, 640)
+#else
+#define LZF_PAIRED_VARIANTS(X) \
+    X(paired24, 4096, 24, 384) \
+    X(paired48, 4096, 48, 640)
+#endif
 #define LZF_EXTP(NAME, RG, S_, T) extern template __global__ void lzf_decompress_paired_kernel<RG, S_, T>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*);
 LZF_PAIRED_VARIANTS(LZF_EXTP)
 #undef LZF_EXTP
+#ifdef LZF_ANALYSIS
 // Region-walk parser + the same copy stage (lz4_decompress_walk.hip): X(name, ring bytes, region bytes, token-list entries).
 template <int RING, int S, int TOKCAP>
 __global__ void lzf_decompress_walk_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
@@ -104,6 +124,7 @@ __global__ void lzf_v6_copy_kernel(const lzf_decompress_job* __restrict__ jobs, 
     extern template __global__ void lzf_v6_copy_kernel<W_>(const lzf_decompress_job*, lzf_job_result*, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint64_t*, const uint64_t*, const uint32_t*, const uint32_t*);
 LZF_V6_VARIANTS(LZF_EXT6)
 #undef LZF_EXT6
+#endif  // LZF_ANALYSIS
 template <int KIND>
 __global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
                                          lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t skip_compact,
@@ -112,9 +133,10 @@ extern template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U32>(const lz
 extern template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U16>(const lzf_compress_job*, lzf_job_result*, uint32_t, uint32_t, const uint32_t*);
 template <bool DRY>
 __global__ void lzf_compress_compact_kernel(const lzf_compress_job* __restrict__ jobs,
-                                            lzf_job_result* __restrict__ results, uint32_t n_jobs, const uint32_t* __restrict__ perm);
-extern template __global__ void lzf_compress_compact_kernel<false>(const lzf_compress_job*, lzf_job_result*, uint32_t, const uint32_t*);
-extern template __global__ void lzf_compress_compact_kernel<true>(const lzf_compress_job*, lzf_job_result*, uint32_t, const uint32_t*);
+                                            lzf_job_result* __restrict__ results, uint32_t n_jobs, const uint32_t* __restrict__ perm,
+                                            uint32_t alone);
+extern template __global__ void lzf_compress_compact_kernel<false>(const lzf_compress_job*, lzf_job_result*, uint32_t, const uint32_t*, uint32_t);
+extern template __global__ void lzf_compress_compact_kernel<true>(const lzf_compress_job*, lzf_job_result*, uint32_t, const uint32_t*, uint32_t);
 // job ordering (aux_kernels.hip): cost probes of the compress jobs and the launch order derived from them
 __global__ void lzf_cost_probe_jobs_kernel(const lzf_compress_job* __restrict__ jobs, lzf_compress_job* __restrict__ probes, uint32_t n,
                                            uint32_t piece, uint32_t parts);
@@ -123,6 +145,8 @@ __global__ void lzf_order_by_cost_kernel(const lzf_compress_job* __restrict__ jo
                                          uint32_t* __restrict__ perm, uint32_t n, uint32_t piece, uint32_t parts);
 __global__ void lzf_xxh32_kernel(const uint8_t* const* __restrict__ ptrs, const uint64_t* __restrict__ lens,
                                  uint32_t* __restrict__ out, uint32_t n);
+__global__ void lzf_xxh32_wave_kernel(const uint8_t* const* __restrict__ ptrs, const uint64_t* __restrict__ lens,
+                                      uint32_t* __restrict__ out, uint32_t n);
 __global__ void lzf_copy_ranges_kernel(const uint8_t* const* __restrict__ src, uint8_t* const* __restrict__ dst,
                                        const uint64_t* __restrict__ len, uint32_t n);
 __global__ void lzf_seed_table_kernel(lzf_u32_table* __restrict__ t, const uint8_t* __restrict__ dict, uint64_t dict_len);

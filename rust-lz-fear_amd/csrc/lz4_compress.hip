@@ -85,11 +85,11 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
         for (uint32_t i = lane; i < TT::kSlots; i += kWave) tab[i] = 0u;
     }
 
-    if (job.input_len > TT::kLimit || job.input_len >= kMaxLen || job.cursor > job.input_len) {
+    if (job.input_len > TT::kLimit || job.input_len >= kMaxLen) {
         status = LZF_CONTRACT;                                           // mod.rs:167
     } else {
         const uint32_t len = (uint32_t)job.input_len;
-        const uint32_t init = (uint32_t)job.cursor;                      // :169
+        const uint32_t init = job.cursor > job.input_len ? len : (uint32_t)job.cursor;   // :169 (a cursor past the end: the loop at :171 never runs)
         uint32_t cursor = init;
         const uint32_t boff = (uint32_t)base_off;   // low 32 bits; overflow is checked at commit
 

@@ -41,7 +41,7 @@ __device__ __forceinline__ uint32_t lt01(uint32_t a, uint32_t b) {
 template <bool DRY>
 __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
     const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
-    const uint32_t* __restrict__ perm) {
+    const uint32_t* __restrict__ perm, uint32_t alone) {
     // slot h = 16-bit half (h & 1) of word h >> 1 | epoch parity of slot h = bit (h & 31) of word kParBase + (h >> 5) | one
     // scratch word per lane: lanes with nothing to do aim their LDS accesses there instead of leaving the instruction (exec-mask
     // bookkeeping is scalar work, and the scalar unit is the bottleneck of this kernel)
@@ -56,7 +56,11 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
     const uint32_t lane = threadIdx.x;
     const lzf_compress_job job = jobs[jid];
     const long long t_start = clock64();
-    if (!compress_job_is_compact(job)) return;      // handled by lzf_compress_wave_kernel
+    if (!compress_job_is_compact(job)) {            // handled by lzf_compress_wave_kernel ...
+        // ... unless the caller promised there are no such jobs (LZF_KINDS_U32_FRESH_ONLY) and that kernel is not launched
+        if (alone && lane == 0) { results[jid].out_len = 0; results[jid].status = LZF_CONTRACT; results[jid].reserved = 0; }
+        return;
+    }
 
     cgu8* __restrict__ in = as_global(job.input);
     int status = LZF_OK;
@@ -630,7 +634,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
     }
 }
 
-template __global__ void lzf_compress_compact_kernel<false>(const lzf_compress_job*, lzf_job_result*, uint32_t, const uint32_t*);
-template __global__ void lzf_compress_compact_kernel<true>(const lzf_compress_job*, lzf_job_result*, uint32_t, const uint32_t*);
+template __global__ void lzf_compress_compact_kernel<false>(const lzf_compress_job*, lzf_job_result*, uint32_t, const uint32_t*, uint32_t);
+template __global__ void lzf_compress_compact_kernel<true>(const lzf_compress_job*, lzf_job_result*, uint32_t, const uint32_t*, uint32_t);
 
 }  // namespace lzf

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_wave_kernel(
 
     int status = LZF_OK;
     uint32_t o = 0;
-    if (job.input_len >= kMaxPos || job.out_existing_len >= kMaxPos || job.prefix_len >= kMaxPos) {
+    if (job.input_len >= kMaxPos || job.out_existing_len >= kMaxPos || job.prefix_len >= kMaxPos || job.out_existing_len > job.out_cap) {
         status = LZF_CONTRACT;   // blocks beyond 2 GiB are outside this kernel's contract
     } else {
         cgu8* __restrict__ in = as_global(job.input);

@@ -83,7 +83,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(
 #ifdef LZF_PHASE_TIMING
     long long g_tph[6] = {0, 0, 0, 0, 0, 0}; uint32_t g_pk_hi = 0;
 #endif
-    if (job.input_len >= kMaxPosB || job.out_existing_len >= kMaxPosB || job.prefix_len >= kMaxPosB) {
+    if (job.input_len >= kMaxPosB || job.out_existing_len >= kMaxPosB || job.prefix_len >= kMaxPosB || job.out_existing_len > job.out_cap) {
         status = LZF_CONTRACT;
     } else {
         cgu8* __restrict__ in = as_global(job.input);

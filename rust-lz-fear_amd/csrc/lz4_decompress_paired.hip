@@ -44,7 +44,7 @@ __global__ __launch_bounds__(128) void lzf_decompress_paired_kernel(
 
     int status = LZF_OK;
     uint32_t o = 0;
-    if (job.input_len >= kMaxPosB || job.out_existing_len >= kMaxPosB || job.prefix_len >= kMaxPosB) {
+    if (job.input_len >= kMaxPosB || job.out_existing_len >= kMaxPosB || job.prefix_len >= kMaxPosB || job.out_existing_len > job.out_cap) {
         status = LZF_CONTRACT;                         // (uniform over the workgroup: no barrier is reached)
     } else {
         cgu8* __restrict__ in = as_global(job.input);

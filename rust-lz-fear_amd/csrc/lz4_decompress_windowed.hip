@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_windowed_kernel(
 #else
 #define LZF_COUNT(x) ((void)0)
 #endif
-    if (job.input_len >= kMaxPosB || job.out_existing_len >= kMaxPosB || job.prefix_len >= kMaxPosB) {
+    if (job.input_len >= kMaxPosB || job.out_existing_len >= kMaxPosB || job.prefix_len >= kMaxPosB || job.out_existing_len > job.out_cap) {
         status = LZF_CONTRACT;
     } else {
         cgu8* __restrict__ in = as_global(job.input);

@@ -12,7 +12,8 @@ OK, UNEXPECTED_END, MEMORY_LIMIT_EXCEEDED, ZERO_DEDUP_OFFSET, INVALID_DEDUP_OFFS
 OUTPUT_FULL, CONTRACT, OUT_CAPACITY = 5, 6, 7
 E_NO_DEVICE, E_HIP, E_INVALID = -1, -2, -3
 TABLE_U32, TABLE_U16 = 0, 1
-KINDS_U32, KINDS_U16 = 1, 2
+KINDS_U32, KINDS_U16, KINDS_U32_FRESH_ONLY = 1, 2, 4
+E_NO_MEMORY = -4
 CJOB_TABLE_READONLY = 1
 
 
@@ -68,13 +69,23 @@ EXPORTS = [
     "lzf_abi_version", "lzf_last_error", "lzf_device_count", "lzf_compress_batch",
     "lzf_decompress_batch", "lzf_table_seed_from_dictionary", "lzf_table_offset", "lzf_table_offset_batch",
     "lzf_chain_decompress_step",
-    "lzf_xxh32_batch", "lzf_copy_ranges", "lzf_compress_batch_host", "lzf_decompress_batch_host",
+    "lzf_xxh32_batch", "lzf_copy_ranges", "lzf_compress_batch_host", "lzf_decompress_batch_host", "lzf_xxh32_batch_host",
 ]
 FRAME_EXPORTS = [
     "lzf_settings_default", "lzf_frame_compress_bound", "lzf_frame_compress", "lzf_frame_read_header",
     "lzf_frame_decompress", "lzf_xxh32", "lzf_frame_assemble", "lzf_frame_compress_many", "lzf_frame_decompress_many",
     "lzf_xxh32_reset", "lzf_xxh32_update", "lzf_xxh32_digest",
+    "lzf_frame_reader_new", "lzf_frame_reader_free", "lzf_frame_reader_info", "lzf_frame_reader_decode_block",
+    "lzf_frame_reader_finished", "lzf_frame_reader_consumed",
+    "lzf_frame_get_stats", "lzf_frame_release_scratch", "lzf_frame_set_host_threads", "lzf_frame_set_memory_budget",
 ]
+
+
+class FrameStats(C.Structure):
+    """lzf_frame_stats"""
+    _fields_ = [(n, C.c_uint64) for n in ("calls", "device_block_hashes", "host_block_hashes", "device_content_hashes",
+                                          "host_content_hashes", "h2d_copies", "d2h_copies", "h2d_bytes", "d2h_bytes",
+                                          "pinned_bytes")]
 
 
 class Xxh32State(C.Structure):
@@ -111,6 +122,7 @@ def lib():
         L.lzf_copy_ranges.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
         L.lzf_compress_batch_host.argtypes = [C.POINTER(CompressJob), C.POINTER(JobResult), C.c_uint32]
         L.lzf_decompress_batch_host.argtypes = [C.POINTER(DecompressJob), C.POINTER(JobResult), C.c_uint32]
+        L.lzf_xxh32_batch_host.argtypes = [C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_uint32]
         L.lzf_settings_default.argtypes = [C.POINTER(Settings)]
         L.lzf_frame_compress_bound.restype = C.c_size_t
         L.lzf_frame_compress_bound.argtypes = [C.POINTER(Settings), C.c_size_t]
@@ -135,8 +147,30 @@ def lib():
         L.lzf_xxh32_digest.restype = C.c_uint32
         L.lzf_frame_assemble.argtypes = [C.POINTER(Settings), C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32),
                                          C.POINTER(C.c_uint32), C.c_uint32, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.lzf_frame_reader_new.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_void_p)]
+        L.lzf_frame_reader_free.argtypes = [C.c_void_p]
+        L.lzf_frame_reader_free.restype = None
+        L.lzf_frame_reader_info.argtypes = [C.c_void_p, C.POINTER(FrameInfo)]
+        L.lzf_frame_reader_info.restype = None
+        L.lzf_frame_reader_decode_block.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.lzf_frame_reader_finished.argtypes = [C.c_void_p]
+        L.lzf_frame_reader_consumed.argtypes = [C.c_void_p]
+        L.lzf_frame_reader_consumed.restype = C.c_size_t
+        L.lzf_frame_get_stats.argtypes = [C.POINTER(FrameStats)]
+        L.lzf_frame_get_stats.restype = None
+        L.lzf_frame_release_scratch.restype = None
+        L.lzf_frame_set_host_threads.argtypes = [C.c_uint32]
+        L.lzf_frame_set_host_threads.restype = None
+        L.lzf_frame_set_memory_budget.argtypes = [C.c_size_t]
+        L.lzf_frame_set_memory_budget.restype = None
         _lib = L
     return _lib
+
+
+def frame_stats():
+    st = FrameStats()
+    lib().lzf_frame_get_stats(C.byref(st))
+    return {n: getattr(st, n) for n, _ in FrameStats._fields_}
 
 
 def check(rc):
@@ -150,6 +184,19 @@ def device_count():
 
 
 # ---- host-buffer batch helpers (bytes in, bytes out) --------------------------------------
+
+def xxh32_blocks_host(blocks):
+    """XXH32 (seed 0) of every bytes object in `blocks`, computed on the device (lzf_xxh32_batch_host)."""
+    blocks = [bytes(b) for b in blocks]
+    n = len(blocks)
+    if n == 0:
+        return []
+    ptrs = (C.c_char_p * n)(*blocks)
+    lens = (C.c_uint64 * n)(*[len(b) for b in blocks])
+    out = (C.c_uint32 * n)()
+    check(lib().lzf_xxh32_batch_host(ptrs, lens, out, n))
+    return list(out)
+
 
 def compress_blocks_host(items):
     """items: list of dict(input=bytes, cursor=int, kind=TABLE_*, table=None|U32Table|U16Table,

@@ -148,7 +148,7 @@ def decompress_frame(frame, dictionary=b"", cap=None):
     return out.raw[: n.value]
 
 
-def decompress_frames(frames, dictionary=b"", caps=None):
+def decompress_frames(frames, dictionary=b"", caps=None, with_consumed=False):
     """`decompress_frame` of every frame through the same launches (lzf_frame_decompress_many).  Returns a list of
     (status, bytes): status 0 and the content, or the inner error kind and what the blocks before it produced —
     exactly what `decompress_frame` returns / raises for each frame alone."""
@@ -168,7 +168,51 @@ def decompress_frames(frames, dictionary=b"", caps=None):
     used = (C.c_size_t * n)()
     st = (C.c_int * n)()
     ffi.check(ffi.lib().lzf_frame_decompress_many(n, ins, lens, dictionary, len(dictionary), outp, capa, olen, used, st))
+    if with_consumed:
+        return [(st[f], outs[f].raw[: olen[f]], used[f]) for f in range(n)]
     return [(st[f], outs[f].raw[: olen[f]]) for f in range(n)]
+
+
+class FrameBlockReader:
+    """The C ABI's block-by-block reader (lzf_frame_reader_*, include/lzfear_frame.h) over a frame in memory:
+    `LZ4FrameReader::new` + `decode_block` (src/framed/decompress.rs:102-161,198-282), one call = one block."""
+
+    def __init__(self, frame):
+        self._frame = bytes(frame)                       # kept alive: the reader points into it
+        self._h = C.c_void_p()
+        rc = ffi.lib().lzf_frame_reader_new(self._frame, len(self._frame), C.byref(self._h))
+        if rc != 0:
+            raise FrameError(rc)
+        self.info = ffi.FrameInfo()
+        ffi.lib().lzf_frame_reader_info(self._h, C.byref(self.info))
+        self._buf = C.create_string_buffer(int(self.info.block_maxsize) * 2 + 64)
+
+    def decode_block(self, dictionary=b""):
+        """One block (b"" once the frame is finished — or for a block that decodes to nothing); raises FrameError."""
+        n = C.c_size_t(0)
+        dictionary = bytes(dictionary)
+        rc = ffi.lib().lzf_frame_reader_decode_block(self._h, dictionary, len(dictionary), self._buf, len(self._buf), C.byref(n))
+        ffi.check(rc)
+        if rc != 0:
+            raise FrameError(rc)
+        return self._buf.raw[: n.value]
+
+    def finished(self):
+        return bool(ffi.lib().lzf_frame_reader_finished(self._h))
+
+    def consumed(self):
+        return int(ffi.lib().lzf_frame_reader_consumed(self._h))
+
+    def close(self):
+        if self._h:
+            ffi.lib().lzf_frame_reader_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class LZ4FrameReader:
@@ -250,9 +294,8 @@ class LZ4FrameReader:
             c = self._read_exact(4)
             if len(c) < 4:
                 raise FrameError(16)
-            if int.from_bytes(c, "little") != ffi.lib().lzf_xxh32(data, len(data), 0):
-                raise FrameError(19)
-        return ("blk", data, compressed)
+            return ("blk", data, compressed, int.from_bytes(c, "little"))       # verified by _refill, on the device
+        return ("blk", data, compressed, None)
 
     def _refill(self):
         """Scan up to `readahead` blocks and decode the compressed ones in one batch (one block at a time
@@ -269,13 +312,19 @@ class LZ4FrameReader:
                 tail = b
                 break
             scanned.append(b)
+        if self._bsum and scanned:                                  # :228-235, all scanned blocks in one device launch
+            got = ffi.xxh32_blocks_host([b[1] for b in scanned])
+            for k, (b, h) in enumerate(zip(scanned, got)):
+                if b[3] != h:
+                    scanned, tail = scanned[:k], FrameError(19)     # reported after the blocks before it
+                    break
         bmax = self.block_size()
         if self._linked and not self._window:
             self._window = self._dict                               # :239-241
         prefix = self._window if self._linked else self._dict       # :238-245
-        items = [dict(input=d, prefix=prefix, limit=bmax, out_cap=bmax + len(d)) for (_, d, comp) in scanned if comp]
+        items = [dict(input=d, prefix=prefix, limit=bmax, out_cap=bmax + len(d)) for (_, d, comp, _c) in scanned if comp]
         res = iter(ffi.decompress_blocks_host(items)) if items else iter(())
-        for (_, d, comp) in scanned:
+        for (_, d, comp, _c) in scanned:
             if comp:
                 rc, out = next(res)
                 if rc != 0:

@@ -367,3 +367,158 @@ def test_many_frames_with_dictionary_roundtrip_linked():
     got = framed.decompress_frames(frames, dictionary=d, caps=[1 << 20] * len(frames))
     assert [rc for rc, _ in got] == [0] * len(frames)
     assert [out for _, out in got] == datas
+
+
+# ---------------------------------------------------------------- round 2: device checksums, staging, reader, budgets
+def test_block_and_content_checksums_are_computed_on_the_device():
+    """The frame drivers hash every block of a call with lzf_xxh32_batch (one launch) and content checksums with one device
+    chain per frame; the host XXH32 is for the header byte only.  lzf_frame_get_stats counts both paths: this test fails
+    if a block checksum (or the content checksum of a frame this small) is ever computed on the host."""
+    from rust_lz_fear_amd import ffi
+    data = [synth.silesia_mix((70 + 3 * k) << 20, ((70 + 3 * k) << 20) + 700_000 + 1111 * k).tobytes() for k in range(5)]
+    data.append(vectors.rng_bytes(5, 200_000))                            # stored blocks: their checksums are over the raw bytes
+    for kw in (dict(block_size=64 << 10, block_checksums=True), dict(block_size=64 << 10, block_checksums=True, independent_blocks=False),
+               dict(block_size=256 << 10, block_checksums=True, dictionary=synth.gen_text_zipf(8, 30000).tobytes())):
+        g, okw = settings_pair(**kw)
+        nblk = sum((len(d) + kw["block_size"] - 1) // kw["block_size"] for d in data)
+        s0 = ffi.frame_stats()
+        frames = g.compress_many(data)
+        s1 = ffi.frame_stats()
+        assert s1["host_block_hashes"] == s0["host_block_hashes"]
+        assert s1["device_block_hashes"] - s0["device_block_hashes"] == nblk
+        dev_c, host_c = s1["device_content_hashes"] - s0["device_content_hashes"], s1["host_content_hashes"] - s0["host_content_hashes"]
+        assert dev_c + host_c == len(data) and (host_c == 0 or "dictionary" in kw)      # dict ++ block layouts hash the (non-contiguous) frame on the workers
+        for d, f in zip(data, frames):
+            assert f == o.frame_compress(d, o.make_settings(**okw))[1]
+        res = framed.decompress_frames(frames, dictionary=kw.get("dictionary", b""))
+        s2 = ffi.frame_stats()
+        assert [r for r in res] == [(0, d) for d in data]
+        assert s2["host_block_hashes"] == s0["host_block_hashes"] and s2["host_content_hashes"] == s1["host_content_hashes"]
+        assert s2["device_block_hashes"] - s1["device_block_hashes"] == nblk
+        assert s2["device_content_hashes"] - s1["device_content_hashes"] == len(data)
+        # a flipped payload byte / checksum byte: BlockChecksumFail at that block, blocks before it delivered, same `consumed`
+        f = bytearray(frames[0]); f[len(f) // 2] ^= 0x40
+        erc, eout, eused = o.frame_decompress(bytes(f), dictionary=kw.get("dictionary", b""), cap=8 << 20)
+        (rc, out, used), = framed.decompress_frames([bytes(f)], dictionary=kw.get("dictionary", b""), caps=[8 << 20], with_consumed=True)
+        assert (rc, out, used) == (erc, eout, eused) and rc == 19
+
+
+def test_consumed_matches_the_reference_reader_on_malformed_frames():
+    """*consumed = what the reference's reader has read from the input when it stops (errors included)."""
+    rng = np.random.default_rng(4242)
+    data = synth.silesia_mix(90 << 20, (90 << 20) + 400_000).tobytes()
+    frames = []
+    for kw in (dict(block_size=64 << 10), dict(block_size=64 << 10, independent_blocks=False, block_checksums=True), dict(block_size=64 << 10, block_checksums=True)):
+        base = o.frame_compress(data, o.make_settings(**kw))[1]
+        frames += [base, base + b"trailing bytes"] + [mutate(rng, base) for _ in range(30)]
+    exp = [o.frame_decompress(f, cap=8 << 20) for f in frames]
+    got = framed.decompress_frames(frames, caps=[8 << 20] * len(frames), with_consumed=True)
+    for (erc, eout, eused), (rc, out, used) in zip(exp, got):
+        assert (rc, out) == (erc, eout)
+        assert used == eused, (rc, used, eused)
+
+
+def test_staging_moves_whole_pieces_not_blocks():
+    """Host staging: one pinned slab, one asynchronous DMA per 4 MiB piece — not one copy per block.  16384 blocks of 4 KiB
+    must not take 16384 host-to-device copies."""
+    from rust_lz_fear_amd import ffi
+    data = synth.silesia_mix(5 << 20, (5 << 20) + (24 << 20)).tobytes()
+    n = 6000
+    blocks = [data[i * 4096:(i + 1) * 4096] for i in range(n)]
+    s0 = ffi.frame_stats()
+    comp = ffi.compress_blocks_host([dict(input=b, out_cap=len(b) + 64) for b in blocks])
+    s1 = ffi.frame_stats()
+    assert all(rc == 0 for rc, _ in comp)
+    assert s1["h2d_copies"] - s0["h2d_copies"] <= 16 and s1["d2h_copies"] - s0["d2h_copies"] <= 16
+    dec = ffi.decompress_blocks_host([dict(input=c, limit=4096, out_cap=4096 + len(c) + 64) for _, c in comp])
+    s2 = ffi.frame_stats()
+    assert [d for _, d in dec] == blocks
+    assert s2["h2d_copies"] - s1["h2d_copies"] <= 16 and s2["d2h_copies"] - s1["d2h_copies"] <= 16
+    assert s2["pinned_bytes"] >= 24 << 20
+    # frames: 40 frames of 1.5 MiB at 64 KiB blocks = 960 blocks, a handful of DMAs each way
+    frames_in = [data[k * 1_500_000:(k + 1) * 1_500_000] for k in range(12)]
+    g, okw = settings_pair(block_size=64 << 10)
+    fr = g.compress_many(frames_in)
+    s3 = ffi.frame_stats()
+    assert s3["h2d_copies"] - s2["h2d_copies"] <= 12 and s3["d2h_copies"] - s2["d2h_copies"] <= 12
+    assert [r for r in framed.decompress_frames(fr)] == [(0, d) for d in frames_in]
+    ffi.lib().lzf_frame_release_scratch()
+    assert ffi.frame_stats()["pinned_bytes"] == 0
+    assert framed.decompress_frames(fr[:2]) == [(0, d) for d in frames_in[:2]]         # scratch comes back on demand
+
+
+def test_decompress_many_memory_budget_slices_and_refuses():
+    """a frame's device footprint is bounded by what its blocks can expand to (255 x compressed size), not by
+    block_maxsize per block; lzf_frame_decompress_many works through the frames in as many passes as its memory budget
+    needs, and a frame that does not fit alone reports LZF_E_NO_MEMORY without taking the others down."""
+    from rust_lz_fear_amd import ffi
+    data = [synth.silesia_mix((100 + k) << 20, ((100 + k) << 20) + 900_000).tobytes() for k in range(9)]
+    frames = [o.frame_compress(d, o.make_settings(block_size=64 << 10, independent_blocks=bool(k % 2)))[1] for k, d in enumerate(data)]
+    big = o.frame_compress(synth.silesia_mix(0, 40 << 20).tobytes(), o.make_settings(block_size=1 << 20))[1]
+    # 20000 five-byte blocks that claim a 4 MiB block size: 80 GB under the old accounting, a few MB now
+    tiny_blk = bytes([0x10, 0x61, 0x01, 0x00]) + b""                      # 1 literal 'a', match len 4 offset 1 -> "aaaaa"
+    many = bytes.fromhex("04224d186070") + bytes([0x73]) + b"".join(len(tiny_blk).to_bytes(4, "little") + tiny_blk for _ in range(20000)) + bytes(4) + (0).to_bytes(4, "little")
+    erc, eout, _ = o.frame_decompress(many, cap=1 << 20)
+    try:
+        ffi.lib().lzf_frame_set_memory_budget(64 << 20)
+        res = framed.decompress_frames(frames + [big] + frames[:2] + [many], caps=[2 << 20] * 9 + [48 << 20] + [2 << 20] * 2 + [1 << 20])
+    finally:
+        ffi.lib().lzf_frame_set_memory_budget(0)
+    assert res[:9] == [(0, d) for d in data] and res[10:12] == [(0, d) for d in data[:2]]
+    assert res[9][0] == ffi.E_NO_MEMORY and res[9][1] == b""
+    assert res[12] == (erc, eout)
+    assert framed.decompress_frames([big], caps=[48 << 20])[0][0] == 0                  # fits under the default budget
+
+
+def test_c_abi_block_reader_is_decode_block():
+    """lzf_frame_reader_* == LZ4FrameReader::new + decode_block, block by block: same blocks, same error kind at the same
+    block, same bytes consumed, dictionary and carried window included."""
+    data = synth.silesia_mix(33 << 20, (33 << 20) + 700_000).tobytes()
+    dic = synth.gen_text_zipf(12, 40000).tobytes()
+    rng = np.random.default_rng(99)
+    cases = []
+    for kw in (dict(block_size=64 << 10), dict(block_size=64 << 10, independent_blocks=False), dict(block_size=256 << 10, block_checksums=True),
+               dict(block_size=64 << 10, independent_blocks=False, dictionary=dic, dictionary_id=3), dict(block_size=64 << 10, dictionary=dic, dictionary_id=3)):
+        f = o.frame_compress(data, o.make_settings(**kw))[1]
+        cases.append((f, kw.get("dictionary", b"")))
+        cases += [(mutate(rng, f), kw.get("dictionary", b"")) for _ in range(6)]
+    cases.append((o.frame_compress(vectors.rng_bytes(3, 150_000), o.make_settings(block_size=64 << 10))[1], b""))       # stored blocks
+    cases.append((o.frame_compress(b"", o.make_settings())[1], b""))
+    for f, d in cases:
+        erc, eout, eused = o.frame_decompress(f, dictionary=d, cap=8 << 20)
+        got, rc, r = b"", 0, None
+        try:
+            r = framed.FrameBlockReader(f)
+            while not r.finished():
+                b = r.decode_block(d)
+                got += b
+                if not b and not r.finished():
+                    break                                     # a block of zero bytes: read_to_end stops here (:52-71,:286)
+                assert len(b) <= r.info.block_maxsize
+        except framed.FrameError as e:
+            rc = e.code
+        assert rc == erc, (rc, erc)
+        assert got == eout
+        if r is not None:
+            assert r.consumed() == eused, (rc, r.consumed(), eused)
+    hdr_err = bytearray(cases[0][0]); hdr_err[0] ^= 1
+    with pytest.raises(framed.FrameError) as e:
+        framed.FrameBlockReader(bytes(hdr_err))
+    assert e.value.code == 17
+
+
+def test_examples_dolz4_delz4_round_trip(tmp_path):
+    """tools/dolz4.py / tools/delz4.py (the reference's examples/dolz4.rs, delz4.rs): file -> .lz4 -> file, and the .lz4 is
+    the frame the reference writes for the same settings."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    data = synth.silesia_mix(20 << 20, (20 << 20) + 9_000_000).tobytes()
+    src = tmp_path / "input.bin"; src.write_bytes(data)
+    lz = tmp_path / "input.bin.lz4"; back = tmp_path / "back.bin"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dolz4.py"), str(src), str(lz)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    frame = lz.read_bytes()
+    assert frame == o.frame_compress(data, o.make_settings(content_size=len(data)))[1]
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "delz4.py"), str(lz), str(back)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert back.read_bytes() == data

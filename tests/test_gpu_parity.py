@@ -157,12 +157,21 @@ def test_decompress_overlap_offsets():
         assert e[0] == 0 and r == e
 
 
-@pytest.mark.parametrize("variant", ["auto", "wave", "staged16", "staged32", "direct4w", "win512", "win1024", "paired16", "paired24", "paired48", "ordered"])
+def _analysis_env(**kw):
+    """The analysis flavour of the library (every kernel generation + the environment knobs that select them;
+    rust-lz-fear_amd/build.py).  The product library has neither."""
+    from rust_lz_fear_amd import build
+    path = build.build_analysis_library()
+    return dict(os.environ, LZF_LIB_PATH=path, **kw)
+
+
+@pytest.mark.parametrize("variant", ["auto", "wave", "staged16", "staged32", "direct4w", "win512", "win1024", "paired16", "paired24", "paired48",
+                                     "walk64", "v4t24", "v5s512", "v6l256", "ordered"])
 def test_every_decompress_kernel_generation(variant):
-    """Both kernel generations (and every ring/region geometry) implement the same contract.
+    """Every kernel generation kept in the analysis library (and every ring/region geometry) implements the same contract.
     "ordered": the longest-first launch order that large batches get, forced on for these small ones."""
     import subprocess, sys
-    env = dict(os.environ, LZF_DECOMPRESS_KERNEL=variant) if variant != "ordered" else dict(os.environ, LZF_DECOMPRESS_ORDER="always")
+    env = _analysis_env(LZF_DECOMPRESS_KERNEL=variant) if variant != "ordered" else _analysis_env(LZF_DECOMPRESS_ORDER="always")
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "variant_check.py")], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -175,11 +184,67 @@ def test_every_compress_kernel(kernel):
     the oracle, over inputs that cross several 64 KiB epochs, skip epochs inside one match and widen the batches.
     "ordered": the cost probe + longest-first launch order that large batches get, forced on for this small one."""
     import subprocess, sys
-    env = dict(os.environ, LZF_COMPRESS_KERNEL=kernel) if kernel != "ordered" else dict(os.environ, LZF_COMPRESS_ORDER="always")
+    env = _analysis_env(LZF_COMPRESS_KERNEL=kernel) if kernel != "ordered" else _analysis_env(LZF_COMPRESS_ORDER="always")
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "compress_variant_check.py")], env=env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "variant ok" in r.stdout
+
+
+def test_product_dispatch_every_batch_size_class():
+    """The product library has no knobs: the batch size alone picks the kernel (paired48 up to 8 blocks per CU, paired24
+    up to 64 per CU, staged16 beyond) and the launch order (longest first beyond 8 blocks per CU for decompress, beyond
+    18 per CU for compress).  Batches on both sides of every threshold, small blocks so the oracle keeps up."""
+    rng = np.random.default_rng(5)
+    base = synth.silesia_mix(0, 1 << 20)
+    def blocks(n):
+        out = []
+        for i in range(n):
+            a = int(rng.integers(0, (1 << 20) - 3000)); ln = int(rng.integers(1, 2500))
+            out.append(base[a:a + ln].tobytes())
+        return out
+    for n in (300, 2100, 4700, 16500):
+        bl = blocks(n)
+        comp = gpu_compress([dict(input=b, out_cap=len(b) + len(b) // 200 + 32) for b in bl])
+        step = max(1, n // 400)
+        for b, (rc, c) in list(zip(bl, comp))[::step]:
+            erc, ec = o.compress2(b, cap=len(b) + len(b) // 200 + 32)
+            assert rc == erc and (rc != 0 or c == ec)
+        ok = [(b, c) for b, (rc, c) in zip(bl, comp) if rc == 0]
+        dec = gpu_decompress([dict(input=c, limit=len(b), out_cap=len(b) + len(c) + 64) for b, c in ok])
+        for (b, c), (rc, d) in zip(ok, dec):
+            assert rc == 0 and d == b
+
+
+def test_oversized_but_ok_literals_and_out_capacity():
+    """raw/decompress.rs:63-67: literals are appended without looking at output_limit; only a match is checked
+    (:96-98).  A block that ends in literals past the limit is Ok and longer than the limit — given room:
+    with out_cap below what the reference's Vec would have grown to, the job reports LZF_OUT_CAPACITY instead."""
+    lit = bytes(range(200))
+    blk = bytes([0xF0, 200 - 15]) + lit                                  # one sequence: 200 literals, end of block
+    m = bytes([0x40]) + b"abcd" + (4).to_bytes(2, "little")             # 4 literals + a match of 4 at offset 4
+    cases = [dict(input=blk, limit=10, out_cap=400), dict(input=blk, limit=0, out_cap=200), dict(input=blk, limit=10, out_cap=199),
+             dict(input=m + blk, limit=8, out_cap=400), dict(input=m + blk, limit=7, out_cap=400), dict(input=m + blk, limit=8, out_cap=100)]
+    res = gpu_decompress(cases)
+    exp = [o.decompress_raw(c["input"], limit=c["limit"], cap=c["out_cap"]) for c in cases]
+    assert res[0] == (ffi.OK, lit) and res[1] == (ffi.OK, lit)
+    assert res[2][0] == ffi.OUT_CAPACITY
+    assert res[3] == (ffi.OK, b"abcdabcd" + lit)
+    assert res[4][0] == ffi.MEMORY_LIMIT_EXCEEDED
+    assert res[5][0] == ffi.OUT_CAPACITY
+    for (rc, out), (erc, eout) in zip(res, exp):
+        assert rc == erc and (rc != 0 or out == eout)
+
+
+def test_compress_cursor_past_the_end_is_ok_and_empty():
+    """compress2 with cursor >= input.len(): the loop at mod.rs:171 never runs -> Ok(()), nothing written, table untouched."""
+    data = synth.text_zipf_64k().tobytes()[:5000]
+    t = ffi.U32Table()
+    res = gpu_compress([dict(input=data, cursor=len(data), out_cap=100), dict(input=data, cursor=len(data) + 7, out_cap=100, table=t),
+                        dict(input=data, cursor=len(data) + 7, out_cap=100, kind=ffi.TABLE_U16)])
+    assert res == [(0, b""), (0, b""), (0, b"")]
+    assert not any(t.dict) and t.offset == 0
+    assert o.compress2(data, cursor=len(data) + 7, cap=100) == (0, b"")
 
 
 def test_decompress_handcrafted_streams():
