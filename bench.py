@@ -160,10 +160,7 @@ def traffic_for(kernel_name, which, n_jobs):
 
 
 def decompress_kernel_name(n_jobs):
-    """What lzf_decompress_batch launches for a batch of n_jobs (capi.hip decompress_variant; 256 CUs)."""
-    v = os.environ.get("LZF_DECOMPRESS_KERNEL", "auto")
-    if v != "auto":
-        return v
+    """What lzf_decompress_batch launches for a batch of n_jobs (capi.hip: 8 / 64 blocks per CU are the thresholds; 256 CUs)."""
     if n_jobs <= 2048:
         return "lzf_decompress_paired_kernel<4096,48,640>"
     return "lzf_decompress_paired_kernel<4096,24,384>" if n_jobs <= 16384 else "lzf_decompress_batched_kernel<4096,16,256,staged>"
@@ -417,8 +414,9 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
 
 
 def end_to_end(bases, ffi):
-    """The C ABI from HOST buffers (lzfear_frame.h): F frames of 16 MiB per call, 4 MiB independent blocks, default settings.
-    PCIe in and out, frame scan / assembly and checksums included — never the bench `value`."""
+    """The C ABI from HOST buffers (lzfear_frame.h): 64 frames of 16 MiB per call, independent blocks, content checksum — at the
+    reference's default block size (4 MiB: 256 blocks per call, so both kernels run at single-block latency) and at 64 KiB
+    blocks (16384 blocks per call).  PCIe in and out, frame scan / assembly and checksums included — never the bench `value`."""
     from rust_lz_fear_amd import framed
     L = ffi.lib()
     F, fsz = 64, 16 << 20
@@ -426,41 +424,46 @@ def end_to_end(bases, ffi):
     datas = [mix[(i * fsz) % (mix.size - fsz):][:fsz].tobytes() for i in range(F)]
     n = len(datas)
     total = sum(len(d) for d in datas)
-    s = framed.CompressionSettings()._struct(None)
-    caps = [L.lzf_frame_compress_bound(C.byref(s), len(d)) for d in datas]
-    outs = [C.create_string_buffer(c) for c in caps]
-    ins = (C.c_char_p * n)(*datas)
-    lens = (C.c_size_t * n)(*[len(d) for d in datas])
-    outp = (C.c_void_p * n)(*[C.cast(o, C.c_void_p) for o in outs])
-    capa = (C.c_size_t * n)(*caps)
-    olen = (C.c_size_t * n)()
-    st = (C.c_int * n)()
-    res = {"frames": n, "frame_bytes": fsz, "settings": "default (4 MiB independent blocks, content checksum)", "buffers": "pageable host memory"}
-    tcs = []
-    for _ in range(3):
-        t = time.perf_counter()
-        rc = L.lzf_frame_compress_many(C.byref(s), n, ins, lens, outp, capa, olen, st)
-        tcs.append(time.perf_counter() - t)
-        assert rc == 0 and not any(st)
-    frames = [outs[f].raw[: olen[f]] for f in range(n)]
-    dcap = [len(d) + 64 for d in datas]
-    douts = [C.create_string_buffer(c) for c in dcap]
-    fin = (C.c_char_p * n)(*frames)
-    flen = (C.c_size_t * n)(*[len(f) for f in frames])
-    doutp = (C.c_void_p * n)(*[C.cast(o, C.c_void_p) for o in douts])
-    dcapa = (C.c_size_t * n)(*dcap)
-    dlen = (C.c_size_t * n)()
-    used = (C.c_size_t * n)()
-    dst = (C.c_int * n)()
-    tds = []
-    for _ in range(3):
-        t = time.perf_counter()
-        rc = L.lzf_frame_decompress_many(n, fin, flen, None, 0, doutp, dcapa, dlen, used, dst)
-        tds.append(time.perf_counter() - t)
-        assert rc == 0 and not any(dst)
-    assert all(douts[f].raw[: dlen[f]] == datas[f] for f in range(0, n, 8))
-    res["frame_compress_many_gibs"] = round(total / sorted(tcs)[1] / 2**30, 3)
-    res["frame_decompress_many_gibs"] = round(total / sorted(tds)[1] / 2**30, 3)
+    res = {"frames": n, "frame_bytes": fsz, "settings": "independent blocks, content checksum (CompressionSettings::default())",
+           "buffers": "pageable host memory", "calls": "median of 5 after one warm-up call (the first call pins the staging slab)"}
+    for bs, key in ((4 << 20, "4MiB_blocks"), (64 << 10, "64KiB_blocks")):
+        s = framed.CompressionSettings().block_size(bs)._struct(None)
+        caps = [L.lzf_frame_compress_bound(C.byref(s), len(d)) for d in datas]
+        outs = [C.create_string_buffer(c) for c in caps]
+        ins = (C.c_char_p * n)(*datas)
+        lens = (C.c_size_t * n)(*[len(d) for d in datas])
+        outp = (C.c_void_p * n)(*[C.cast(o, C.c_void_p) for o in outs])
+        capa = (C.c_size_t * n)(*caps)
+        olen = (C.c_size_t * n)()
+        st = (C.c_int * n)()
+        tcs = []
+        for _ in range(6):
+            t = time.perf_counter()
+            rc = L.lzf_frame_compress_many(C.byref(s), n, ins, lens, outp, capa, olen, st)
+            tcs.append(time.perf_counter() - t)
+            assert rc == 0 and not any(st)
+        frames = [outs[f].raw[: olen[f]] for f in range(n)]
+        dcap = [len(d) + 64 for d in datas]
+        douts = [C.create_string_buffer(c) for c in dcap]
+        fin = (C.c_char_p * n)(*frames)
+        flen = (C.c_size_t * n)(*[len(f) for f in frames])
+        doutp = (C.c_void_p * n)(*[C.cast(o, C.c_void_p) for o in douts])
+        dcapa = (C.c_size_t * n)(*dcap)
+        dlen = (C.c_size_t * n)()
+        used = (C.c_size_t * n)()
+        dst = (C.c_int * n)()
+        tds = []
+        for _ in range(6):
+            t = time.perf_counter()
+            rc = L.lzf_frame_decompress_many(n, fin, flen, None, 0, doutp, dcapa, dlen, used, dst)
+            tds.append(time.perf_counter() - t)
+            assert rc == 0 and not any(dst)
+        assert all(douts[f].raw[: dlen[f]] == datas[f] for f in range(0, n, 8))
+        res[key] = {"frame_compress_many_gibs": round(total / sorted(tcs[1:])[2] / 2**30, 3),
+                    "frame_decompress_many_gibs": round(total / sorted(tds[1:])[2] / 2**30, 3),
+                    "frame_compress_many_ms": round(sorted(tcs[1:])[2] * 1e3, 1), "frame_decompress_many_ms": round(sorted(tds[1:])[2] * 1e3, 1)}
+        del outs, douts
+    L.lzf_frame_release_scratch()
     return res
 
 

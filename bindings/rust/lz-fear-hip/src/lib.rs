@@ -55,8 +55,12 @@ pub mod raw {
     /// `raw::decompress_raw` (src/raw/decompress.rs:58-59): appends to `output`, which is also history.
     pub fn decompress_raw(input: &[u8], prefix: &[u8], output: &mut Vec<u8>, output_limit: usize) -> Result<(), DecodeError> {
         let existing = output.len();
-        let cap = output_limit.min(isize::MAX as usize - input.len()) + input.len(); // limit + C
-        output.resize(cap.max(existing), 0);
+        // room for what this call can append: at most 255 bytes per input byte (a run-length byte is the densest code,
+        // raw/decompress.rs:40-56) and at most up to the limit plus the literals that may overshoot it —
+        // never `output_limit` itself, which callers set to usize::MAX-like values
+        let grow = input.len().saturating_mul(255).saturating_add(16)
+            .min(output_limit.saturating_sub(existing).saturating_add(input.len()));
+        output.resize(existing + grow, 0);
         let job = sys::lzf_decompress_job {
             input: input.as_ptr(), input_len: input.len() as u64,
             prefix: prefix.as_ptr(), prefix_len: prefix.len() as u64,
@@ -66,7 +70,7 @@ pub mod raw {
         let mut res = sys::lzf_job_result::default();
         let rc = unsafe { sys::lzf_decompress_batch_host(&job, &mut res, 1) };
         assert_eq!(rc, 0, "lzfear_hip: no device / HIP error");
-        output.truncate(res.out_len as usize);
+        output.truncate((res.out_len as usize).min(output.len()).max(existing));
         match res.status {
             sys::LZF_OK => Ok(()),
             sys::LZF_UNEXPECTED_END => Err(DecodeError::UnexpectedEnd),

@@ -483,3 +483,25 @@ def test_copy_ranges_stored_blocks():
     for n, a, b in zip(lens, so, do):
         exp[b:b + n] = s[a:a + n]
     assert np.array_equal(dst.cpu().numpy(), exp)
+
+
+def test_blocks_from_another_encoder_hc_fixtures():
+    """tests/golden/hc_blocks.*: blocks written by liblz4's LZ4_compress_HC (levels 9, 12) and LZ4_compress_fast — parse
+    shapes the greedy lz-fear encoder never produces.  The GPU decodes the committed bytes to the regenerated inputs, at
+    the exact limit, one byte under it (MemoryLimitExceeded like the oracle) and with a prefix cut off the front."""
+    J = json.load(open(os.path.join(GOLD, "hc_blocks.json")))
+    blob = open(os.path.join(GOLD, "hc_blocks.bin"), "rb").read()
+    items, want = [], []
+    for b in J["blocks"]:
+        comp = blob[b["offset"]: b["offset"] + b["length"]]
+        assert [len(comp), "%08x" % o.xxh32(comp)] == b["comp"]
+        data = eval(b["input"], {"synth": synth}).tobytes()
+        assert [len(data), "%08x" % o.xxh32(data)] == b["in"]
+        items.append(dict(input=comp, limit=len(data), out_cap=len(data) + len(comp) + 64)); want.append((0, data))
+        items.append(dict(input=comp, limit=len(data) - 1, out_cap=len(data) + len(comp) + 64)); want.append(o.decompress_raw(comp, limit=len(data) - 1, cap=len(data) + len(comp) + 64))
+        items.append(dict(input=comp[: len(comp) // 2], limit=len(data), out_cap=len(data) + len(comp) + 64)); want.append(o.decompress_raw(comp[: len(comp) // 2], limit=len(data), cap=len(data) + len(comp) + 64))
+    got = gpu_decompress(items)
+    for (rc, out), (erc, eout), it in zip(got, want, items):
+        assert rc == erc
+        if rc == 0:
+            assert out == eout

@@ -278,3 +278,17 @@ def test_prefix_and_table_carry_equals_linked_frame_blocks():
         else:
             body += (len(blk) | 0x80000000).to_bytes(4, "little") + blk
     assert f[7:-4] == body
+
+
+def test_hc_fixtures_decode_with_the_oracle():
+    """tests/golden/hc_blocks.*: blocks from liblz4's HC / fast encoders decode to the regenerated inputs."""
+    from rust_lz_fear_amd import synth
+    J = json.load(open(os.path.join(GOLD, "hc_blocks.json")))
+    blob = open(os.path.join(GOLD, "hc_blocks.bin"), "rb").read()
+    assert len(J["blocks"]) == 18
+    for b in J["blocks"]:
+        comp = blob[b["offset"]: b["offset"] + b["length"]]
+        assert [len(comp), "%08x" % o.xxh32(comp)] == b["comp"]
+        data = eval(b["input"], {"synth": synth}).tobytes()
+        assert [len(data), "%08x" % o.xxh32(data)] == b["in"]
+        assert o.decompress_raw(comp, limit=len(data)) == (0, data)

@@ -1,3 +1,5 @@
+# kernel-variant knobs live in the analysis flavour of the library (rust-lz-fear_amd/build.py)
+export LZF_LIB_PATH="${LZF_LIB_PATH:-${GRAFT_REPO_ROOT:-$PWD}/rust-lz-fear_amd/liblzfear_hip_analysis.so}"
 # usage (GPU box): bash tools/gpu_v4_check.sh  — parity of the v4 variants + timing vs paired24
 for v in v4t24 v4t48 v4t24w8 v4w64 v4w96; do
   echo "== $v" ; LZF_DECOMPRESS_KERNEL=$v timeout 600 python tests/variant_check.py 2>&1 | tail -3

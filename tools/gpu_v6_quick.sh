@@ -1,3 +1,5 @@
+# kernel-variant knobs live in the analysis flavour of the library (rust-lz-fear_amd/build.py)
+export LZF_LIB_PATH="${LZF_LIB_PATH:-${GRAFT_REPO_ROOT:-$PWD}/rust-lz-fear_amd/liblzfear_hip_analysis.so}"
 for v in v6l256; do echo "== $v"; LZF_DECOMPRESS_KERNEL=$v timeout 300 python tests/variant_check.py 2>&1 | tail -1; done
 echo "== stress v6l256"; LZF_DECOMPRESS_KERNEL=v6l256 timeout 600 python tests/stress_parity.py 2 95 2>&1 | tail -1
 bash tools/time_variants.sh 240 paired24 v6l256 v6l256w6

@@ -1,3 +1,5 @@
+# kernel-variant knobs live in the analysis flavour of the library (rust-lz-fear_amd/build.py)
+export LZF_LIB_PATH="${LZF_LIB_PATH:-${GRAFT_REPO_ROOT:-$PWD}/rust-lz-fear_amd/liblzfear_hip_analysis.so}"
 # SQ instruction counters of one decompress variant across analysis libraries:
 #   bash tools/pmc_libs.sh VARIANT lib.so...     -> gpurun_out/pmc5/<libname>.txt
 set -u

@@ -1,3 +1,5 @@
+# kernel-variant knobs live in the analysis flavour of the library (rust-lz-fear_amd/build.py)
+export LZF_LIB_PATH="${LZF_LIB_PATH:-${GRAFT_REPO_ROOT:-$PWD}/rust-lz-fear_amd/liblzfear_hip_analysis.so}"
 # SQ instruction counters of the v6 copy kernel across analysis libraries: bash tools/pmc_libs6.sh VARIANT lib.so...
 set -u
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/pmc8; cd /tmp; export TMPDIR=/tmp; export LZF_V6_SLICE=16384

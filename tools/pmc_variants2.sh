@@ -1,3 +1,5 @@
+# kernel-variant knobs live in the analysis flavour of the library (rust-lz-fear_amd/build.py)
+export LZF_LIB_PATH="${LZF_LIB_PATH:-${GRAFT_REPO_ROOT:-$PWD}/rust-lz-fear_amd/liblzfear_hip_analysis.so}"
 # SQ instruction counters of decompress kernel variants (selected by name, same library):
 #   bash tools/pmc_variants2.sh variant...     -> gpurun_out/pmc4/<variant>.txt   (40 copies = 1960 blocks, 468.5 M sequences... see NSEQ)
 set -u

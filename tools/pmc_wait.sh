@@ -1,3 +1,5 @@
+# kernel-variant knobs live in the analysis flavour of the library (rust-lz-fear_amd/build.py)
+export LZF_LIB_PATH="${LZF_LIB_PATH:-${GRAFT_REPO_ROOT:-$PWD}/rust-lz-fear_amd/liblzfear_hip_analysis.so}"
 # SQ wait/active counters of a decompress variant: bash tools/pmc_wait.sh VARIANT [lib]
 set -u
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/pmc6; cd /tmp; export TMPDIR=/tmp

@@ -1,25 +1,54 @@
-# Regenerates the round's measurement artifacts on the GPU box (run through gpurun from the repo root):
-#   gpurun_out/r01/bench_default.json          python bench.py (the driver's default invocation)
-#   gpurun_out/r01/kernel_stats.txt            rocprofv3 --kernel-trace --stats of the same command
-#   gpurun_out/r01/pmc_{fetch,write}.csv       separate --pmc passes (40 copies, 1 step, the kernel the full-size bench
-#                                               selects: paired24) for HBM traffic
+#!/bin/bash
+# Regenerates the round's measurement artifacts on the GPU box (run through gpurun from the repo root), product library only:
+#   gpurun_out/r02/bench_default.json          python bench.py (the driver's default invocation)
+#   gpurun_out/r02/kernel_stats.txt            rocprofv3 --kernel-trace --stats of the same command
+#   gpurun_out/r02/pmc_{FETCH,WRITE}_SIZE.txt  separate --pmc passes of the SAME workload (240 copies, 1 step: the kernels and
+#                                               job counts of the default run) for HBM traffic
+#   gpurun_out/r02/hbm_traffic.json            the two passes as the file bench.py reads (copy to profiles/r02_hbm_traffic.json)
+#   gpurun_out/r02/bench_config4.json          python bench.py --workload config4
+#   gpurun_out/r02/bench_20distinct.json       seed-sensitivity check: 20 copies, all with their own seeds
 set -u
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r01; rm -rf $O; mkdir -p $O
-cd $R && timeout 900 python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log > $O/bench_default.json
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; rm -rf $O; mkdir -p $O
+cd $R && timeout 1500 python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log > $O/bench_default.json
 cd /tmp; export TMPDIR=/tmp
-(cd $R && timeout 900 rocprofv3 --kernel-trace --stats -d $O/prof -o x -- python bench.py > $O/prof.log 2>&1)
+(cd $R && timeout 1500 rocprofv3 --kernel-trace --stats -d $O/prof -o x -- python bench.py --no-cpu --no-e2e > $O/prof.log 2>&1)
 DB=$(ls $O/prof/*/x_results.db $O/prof/x_results.db 2>/dev/null | head -1)
 [ -n "$DB" ] && python $R/profiles/summarize_rocpd.py $DB > $O/kernel_stats.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  (cd $R && LZF_DECOMPRESS_KERNEL=paired24 timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python bench.py --copies 40 --steps 1 --warmup 0 --no-cpu --no-verify > $O/pmc_$c.log 2>&1)
+  (cd $R && timeout 1500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python bench.py --steps 1 --warmup 0 --no-cpu --no-e2e --no-verify > $O/pmc_$c.log 2>&1)
   f=$(ls $O/pmc_$c/*/*_counter_collection.csv 2>/dev/null | head -1)
   [ -n "$f" ] && python - "$f" "$c" > $O/pmc_$c.txt <<'PY'
 import csv, sys, collections
-agg = collections.defaultdict(float); cnt = collections.Counter()
+agg = collections.defaultdict(float); cnt = collections.Counter(); grid = {}
 for r in csv.DictReader(open(sys.argv[1])):
     if 'lzf' in r['Kernel_Name']:
-        k = r['Kernel_Name'][:80]; agg[k] += float(r['Counter_Value']); cnt[k] += 1
-for k in agg: print(sys.argv[2], k, 'dispatches', cnt[k], 'sum', agg[k], 'per_dispatch', agg[k] / cnt[k])
+        k = r['Kernel_Name'][:90]; agg[k] += float(r['Counter_Value']); cnt[k] += 1; grid[k] = r.get('Grid_Size', '')
+for k in agg: print(sys.argv[2], '|', k, '| dispatches', cnt[k], '| grid', grid[k], '| sum', agg[k], '| per_dispatch', agg[k] / cnt[k])
 PY
 done
-cat $O/bench_default.json | cut -c1-600; cat $O/kernel_stats.txt | head -8; cat $O/pmc_FETCH_SIZE.txt $O/pmc_WRITE_SIZE.txt
+python - $O <<'PY'
+import json, os, re, sys
+O = sys.argv[1]
+line = json.loads(open(os.path.join(O, "bench_default.json")).read())
+def per_dispatch(counter, needle):
+    best = None
+    for l in open(os.path.join(O, f"pmc_{counter}.txt")):
+        p = [x.strip() for x in l.split("|")]
+        if needle in p[1]:
+            best = (p[1], float(p[5].split()[-1]), p[3].split()[-1])
+    return best
+out = {"_what": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace) of `python bench.py --steps 1 --warmup 0 --no-cpu --no-e2e --no-verify` "
+                "(the default workload: same kernels, same job counts as the bench line) on MI355X, round 2; per dispatch, in the counters' KB units (x1024 bytes). "
+                "gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half of the bytes of wide streaming reads; bench.py uses 2 x FETCH + WRITE as the upper bound."}
+dk = line["roofline"]["kernel"].split("<")[0]
+for which, needle, jobs in (("decompress", dk, line["kernel_only"]["blocks_per_gpu"]), ("compress", "lzf_compress_compact_kernel<false>", line["config"]["blocks_per_gpu"])):
+    f, w = per_dispatch("FETCH_SIZE", needle), per_dispatch("WRITE_SIZE", needle)
+    if f and w:
+        out[which] = {"kernel": line["roofline"]["kernel"] if which == "decompress" else "lzf_compress_compact_kernel<false>", "kernel_as_profiled": f[0], "grid": f[2],
+                      "jobs": jobs, "FETCH_SIZE_KB": f[1], "WRITE_SIZE_KB": w[1]}
+json.dump(out, open(os.path.join(O, "hbm_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1)[:1500])
+PY
+cd $R && timeout 900 python bench.py --workload config4 --no-cpu > $O/bench_config4.log 2>&1; tail -1 $O/bench_config4.log > $O/bench_config4.json
+cd $R && timeout 900 python bench.py --copies 20 --distinct 20 --no-cpu --no-e2e > $O/bench_20distinct.log 2>&1; tail -1 $O/bench_20distinct.log > $O/bench_20distinct.json
+cut -c1-900 $O/bench_default.json; head -12 $O/kernel_stats.txt; cat $O/pmc_FETCH_SIZE.txt $O/pmc_WRITE_SIZE.txt; cut -c1-400 $O/bench_config4.json; cut -c1-400 $O/bench_20distinct.json
