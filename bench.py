@@ -265,7 +265,7 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
     d_cres = torch.zeros(nblk * 16, dtype=torch.uint8, device=dev)
 
     def compress_step():
-        device.compress_batch(d_cj, d_cres, nblk, ffi.KINDS_U32)
+        device.compress_batch(d_cj, d_cres, nblk, ffi.KINDS_U32 | ffi.KINDS_U32_FRESH_ONLY)
 
     c_steps = max(1, min(args.steps, 3))
     compress_step()
@@ -501,8 +501,14 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
     state = {}
     header = lzdist.frame_header(content_checksum=False, block_size=BS)
 
+    kev = []
+
     def step():
-        device.compress_batch(d_cj, d_cres, nloc, ffi.KINDS_U32)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        device.compress_batch(d_cj, d_cres, nloc, ffi.KINDS_U32 | ffi.KINDS_U32_FRESH_ONLY)
+        b.record()
+        kev.append((a, b))
         state["frame_len"], state["comp_total"] = lzdist.gather_frame_device(d_cres, comp, src, BS, nloc, nblk_all, frame, dist, rank, world, device, header)
 
     for _ in range(args.warmup):
@@ -511,6 +517,7 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
+    kev.clear()
     t1 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -523,6 +530,7 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
     if dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t[0])
+    k_ms = sum(a.elapsed_time(b) for a, b in kev) / max(len(kev), 1)      # the compress call of this rank (cost probe + kernel), HIP events
     # ---- check: the frame's head == the oracle's frame of the same first blocks (rank 0 holds them)
     verified = None
     if rank == 0 and not args.no_verify:
@@ -540,6 +548,18 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
         return None
     total_bytes = float(nblk_all) * BS
     wire = state["comp_total"] * (world - 1) / max(world, 1)
+    # roofline of the dominant kernel (this rank's launch): reads N, writes C
+    alg = float(nloc) * BS + state["comp_total"] * nloc / max(nblk_all, 1)
+    achieved = alg / (k_ms * 1e-3) / 1e9
+    cpu = None
+    if world == 1 and not args.no_cpu:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        n_s = min(nloc, 16)
+        raw_blocks = [src[i * BS:(i + 1) * BS].cpu().numpy() for i in range(n_s)]
+        res = d_cres.view(torch.int64).view(-1, 2)[:n_s].cpu().numpy()
+        comp_blocks = [comp[i * BS: i * BS + int(res[i, 0])].cpu().numpy() for i in range(n_s)]
+        cpu = cpu_baseline(raw_blocks, comp_blocks, args.cpu_seconds)
+        cpu["value"], cpu["unit"] = cpu["compress_value"], "GiB/s (compress, uncompressed bytes; all hardware threads)"
     return {
         "metric": METRIC,
         "value": round(total_bytes * args.steps / elapsed_max / 2**30, 3), "unit": "GiB/s (uncompressed bytes compressed into one frame per second)",
@@ -553,6 +573,10 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
                                (nblk_all, total_bytes / 2**30, total_bytes / max(state["comp_total"], 1)),
                    "blocks": nblk_all, "block_size": BS, "parallelism": f"block ranges x{world}, all-gather over RCCL",
                    "frame_bytes": int(state["frame_len"]), "wire_bytes_in_per_rank": int(wire), "verified_against_oracle_prefix": verified},
+        "roofline": {"bound": "hbm", "kernel": "lzf_compress_compact_kernel<false>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_for("lzf_compress_compact_kernel<false>", "compress", nloc),
+                     "algorithmic_bytes_per_launch": alg, "kernel_ms": round(k_ms, 4)},
+        "cpu_baseline": cpu,
     }
 
 

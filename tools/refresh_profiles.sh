@@ -2,8 +2,8 @@
 # Regenerates the round's measurement artifacts on the GPU box (run through gpurun from the repo root), product library only:
 #   gpurun_out/r02/bench_default.json          python bench.py (the driver's default invocation)
 #   gpurun_out/r02/kernel_stats.txt            rocprofv3 --kernel-trace --stats of the same command
-#   gpurun_out/r02/pmc_{FETCH,WRITE}_SIZE.txt  separate --pmc passes of the SAME workload (240 copies, 1 step: the kernels and
-#                                               job counts of the default run) for HBM traffic
+#   gpurun_out/r02/pmc_{FETCH,WRITE}_SIZE.txt  separate --pmc passes at 48 copies (1 step; 2352 compressed blocks: the same kernels
+#                                               as the default run — counter collection at 240 copies does not finish) for HBM traffic
 #   gpurun_out/r02/hbm_traffic.json            the two passes as the file bench.py reads (copy to profiles/r02_hbm_traffic.json)
 #   gpurun_out/r02/bench_config4.json          python bench.py --workload config4
 #   gpurun_out/r02/bench_20distinct.json       seed-sensitivity check: 20 copies, all with their own seeds
@@ -15,7 +15,8 @@ cd /tmp; export TMPDIR=/tmp
 DB=$(ls $O/prof/*/x_results.db $O/prof/x_results.db 2>/dev/null | head -1)
 [ -n "$DB" ] && python $R/profiles/summarize_rocpd.py $DB > $O/kernel_stats.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  (cd $R && timeout 1500 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python bench.py --steps 1 --warmup 0 --no-cpu --no-e2e --no-verify > $O/pmc_$c.log 2>&1)
+  (cd $R && timeout 420 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python bench.py --copies 48 --distinct 1 --steps 1 --warmup 0 --no-cpu --no-e2e --no-verify > $O/pmc_$c.log 2>&1)
+  rm -rf $O/pmc_$c/*/*.db
   f=$(ls $O/pmc_$c/*/*_counter_collection.csv 2>/dev/null | head -1)
   [ -n "$f" ] && python - "$f" "$c" > $O/pmc_$c.txt <<'PY'
 import csv, sys, collections
@@ -29,7 +30,7 @@ done
 python - $O <<'PY'
 import json, os, re, sys
 O = sys.argv[1]
-line = json.loads(open(os.path.join(O, "bench_default.json")).read())
+line = json.loads([l for l in open(os.path.join(O, "pmc_FETCH_SIZE.log")) if l.startswith('{"metric"')][-1])     # the profiled run's own line: its kernels and job counts
 def per_dispatch(counter, needle):
     best = None
     for l in open(os.path.join(O, f"pmc_{counter}.txt")):
@@ -37,8 +38,8 @@ def per_dispatch(counter, needle):
         if needle in p[1]:
             best = (p[1], float(p[5].split()[-1]), p[3].split()[-1])
     return best
-out = {"_what": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace) of `python bench.py --steps 1 --warmup 0 --no-cpu --no-e2e --no-verify` "
-                "(the default workload: same kernels, same job counts as the bench line) on MI355X, round 2; per dispatch, in the counters' KB units (x1024 bytes). "
+out = {"_what": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace) of `python bench.py --copies 48 --distinct 1 --steps 1 --warmup 0 --no-cpu --no-e2e --no-verify` "
+                "(48 copies: the same kernels as the default 240-copy run; bench.py scales by job count) on MI355X, round 2; per dispatch, in the counters' KB units (x1024 bytes). "
                 "gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half of the bytes of wide streaming reads; bench.py uses 2 x FETCH + WRITE as the upper bound."}
 dk = line["roofline"]["kernel"].split("<")[0]
 for which, needle, jobs in (("decompress", dk, line["kernel_only"]["blocks_per_gpu"]), ("compress", "lzf_compress_compact_kernel<false>", line["config"]["blocks_per_gpu"])):
