@@ -65,6 +65,12 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
     cgu8* __restrict__ in = as_global(job.input);
     int status = LZF_OK;
     uint32_t work = 0;      // DRY: probe batches + sequences, the two things a block's time is made of
+#ifdef LZF_DBG_PATHS        // analysis: which path each sequence / batch took; the five counts replace the first 20 output bytes
+    uint32_t pc_straight = 0, pc_ext = 0, pc_tail_short = 0, pc_tail_long = 0, pc_bfast = 0, pc_bgen = 0;
+#define PCOUNT(x) (++(x))
+#else
+#define PCOUNT(x) do { } while (0)
+#endif
 #ifdef LZF_PHASE_TIMING
     long long g_tph[6] = {0, 0, 0, 0, 0, 0};
 #endif
@@ -179,6 +185,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 if (c < f_lo) return true;
                 if (c + bw > f_hi) return true;                                   // (len < 2^31: no wrap)
                 if (DRY) ++work;
+                PCOUNT(pc_bfast);
                 const bool inb = lane < bw;
                 const uint32_t ck = c + lane;
                 const uint32_t have = bw > kProbeLanes ? bw : kProbeLanes;   // lanes holding 16 input bytes (c + 40 + bw <= len: readable)
@@ -277,6 +284,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                         if (lane == L2 + nl2 + 2u) byte = off2 >> 8;
                         if (!DRY && lane < L2 + nl2 + 3u) s.out[s.pos + lane] = (uint8_t)byte;
                         s.pos += L2 + nl2 + 3u;
+                        PCOUNT(pc_straight);
                         straight = true;
                     } else {
                         m = wm;
@@ -326,6 +334,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                             if (lane == L3 + 2u) byte = off3 >> 8;
                             if (!DRY && lane < tot3) s.out[s.pos + lane] = (uint8_t)byte;
                             s.pos += tot3;
+                            PCOUNT(pc_ext);
                             continue;
                         }
                     }
@@ -334,6 +343,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             // ================= search: speculative batches of the :177-232 loop
             if (!found) for (;;) {
                 if (DRY) ++work;
+                PCOUNT(pc_bgen);
                 { const uint32_t eb = c >> 16; if (eb != swept) sweep_to(eb); }        // the batch base enters a new 64 KiB epoch
                 // Common case, decided once per batch with scalar compares: first batch of a run, not at
                 // the block's edges.  Then every lane is a plain probe (no schedule arithmetic, no end-of-
@@ -592,9 +602,11 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 if (lane == L + 2u) byte = dup_offset >> 8;
                 if (!DRY && lane < total) s.out[s.pos + lane] = (uint8_t)byte;
                 s.pos += total;
+                PCOUNT(pc_tail_short);
                 CPHASE(3);
                 continue;
             }
+            PCOUNT(pc_tail_long);
             const uint32_t nl = lsic_len(L), ne = lsic_len(extra);
             const uint32_t total = 1u + nl + L + 2u + ne;
             if (s.cap - s.pos < total) { status = LZF_OUTPUT_FULL; break; }
@@ -623,6 +635,12 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             CPHASE(3);
         }
     }
+#ifdef LZF_DBG_PATHS
+    if (lane == 0 && job.out_cap >= 24u) {
+        LZF_GLOBAL uint32_t* pc = (LZF_GLOBAL uint32_t*)as_global(job.out);
+        pc[0] = pc_straight; pc[1] = pc_ext; pc[2] = pc_tail_short; pc[3] = pc_tail_long; pc[4] = pc_bfast; pc[5] = pc_bgen;
+    }
+#endif
     if (lane == 0) {
         results[jid].out_len = s.pos;
         results[jid].status = status;
