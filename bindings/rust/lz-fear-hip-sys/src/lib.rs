@@ -86,4 +86,15 @@ extern "C" {
     pub fn lzf_xxh32_batch(d_ptrs: *const *const u8, d_lens: *const u64, d_out: *mut u32, n: u32,
                            hip_stream: *mut c_void) -> c_int;
     pub fn lzf_copy_ranges(d_src: *const *const u8, d_dst: *const *mut u8, d_len: *const u64, n: u32, max_len: u64, hip_stream: *mut c_void) -> c_int;
+    pub fn lzf_xxh32_batch_host(ptrs: *const *const u8, lens: *const u64, out: *mut u32, n: u32) -> c_int;
+    // lzfear_frame.h: the block-by-block reader (LZ4FrameReader::new + decode_block) and the staging controls
+    pub fn lzf_frame_reader_new(input: *const u8, in_len: usize, r: *mut *mut lzf_frame_reader) -> c_int;
+    pub fn lzf_frame_reader_free(r: *mut lzf_frame_reader);
+    pub fn lzf_frame_reader_decode_block(r: *mut lzf_frame_reader, dict: *const u8, dict_len: usize,
+                                         out: *mut u8, out_cap: usize, out_len: *mut usize) -> c_int;
+    pub fn lzf_frame_reader_finished(r: *const lzf_frame_reader) -> c_int;
+    pub fn lzf_frame_reader_consumed(r: *const lzf_frame_reader) -> usize;
+    pub fn lzf_frame_release_scratch();
+    pub fn lzf_frame_set_host_threads(n: u32);
+    pub fn lzf_frame_set_memory_budget(bytes: usize);
 }
