@@ -486,7 +486,7 @@ int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint
     Staging& sg = Staging::get();
     std::lock_guard<std::mutex> guard(sg.lock());
     TRACE_BEGIN();
-    hipStream_t cs = sg.stream(0), hs = sg.stream(1);
+    hipStream_t cs = sg.stream(0), hs = sg.stream(3);
     if (!cs || !hs) return LZF_E_HIP;
     if (!sg.pinned(in_total > pack_bound ? in_total : pack_bound)) return LZF_E_HIP;
     TRACE("c: pinned slab");
@@ -713,7 +713,7 @@ inline size_t block_out_bound(size_t bmax, size_t len) { const size_t e = 255 * 
 // One pass over frames [f0, f1): everything on the device at once.
 int decompress_group(Staging& sg, std::vector<DFrame>& fr, uint32_t f0, uint32_t f1, const uint8_t* const* in, const size_t* in_len,
                      const uint8_t* dict, size_t dict_len, uint8_t* const* out, const size_t* out_cap, size_t* out_len, size_t* consumed, int* status) {
-    hipStream_t cs = sg.stream(0), hs = sg.stream(1);
+    hipStream_t cs = sg.stream(0), hs = sg.stream(3);
     if (!cs || !hs) return LZF_E_HIP;
     TRACE_BEGIN();
     size_t in_total = 0, out_total = 0, max_steps = 0, n_sums = 0, pack_bound = 0;

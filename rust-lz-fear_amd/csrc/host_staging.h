@@ -31,7 +31,7 @@ public:
     uint8_t* mailbox(size_t bytes);                    // a second, small pinned buffer for results that come back asynchronously
     void* device(int slot, size_t bytes);              // device scratch slot (0..kSlots-1), at least `bytes` long
     static constexpr int kSlots = 16;
-    hipStream_t stream(int i);                         // 0: compute, 1..2: copy engines (non-blocking streams)
+    hipStream_t stream(int i);                         // 0: compute, 1..2: copy engines, 3: checksums (non-blocking streams)
     void release();                                    // give everything back (lzf_host_release_scratch)
     void set_threads(unsigned n);                      // worker threads for the next calls (0 = default)
     size_t pinned_capacity() const { return pin_cap_; }
@@ -55,7 +55,7 @@ private:
     uint8_t* pin_ = nullptr; size_t pin_cap_ = 0;
     uint8_t* mail_ = nullptr; size_t mail_cap_ = 0;
     void* dev_[kSlots] = {}; size_t dev_cap_[kSlots] = {};
-    hipStream_t streams_[3] = {};
+    hipStream_t streams_[4] = {};
     std::vector<hipEvent_t> events_;
 public:
     struct Counters { uint64_t h2d_copies, d2h_copies, h2d_bytes, d2h_bytes; } counters = {0, 0, 0, 0};
