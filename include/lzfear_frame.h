@@ -135,7 +135,7 @@ typedef struct lzf_frame_stats {
 } lzf_frame_stats;
 void lzf_frame_get_stats(lzf_frame_stats* st);
 /* The drivers keep their pinned slab and device scratch between calls (allocating gigabytes costs more than the
- * kernels); this gives everything back.  Calls are serialised per process. */
+ * kernels); this gives everything back.  Calls are serialised per device (one slab per device). */
 void lzf_frame_release_scratch(void);
 void lzf_frame_set_host_threads(uint32_t n);      /* memcpy / hashing workers, 0 = default (12 on a large host) */
 /* Device memory one pass of lzf_frame_decompress_many may use (0 = half of what is free): more frames than fit are

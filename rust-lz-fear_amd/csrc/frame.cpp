@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <mutex>
@@ -101,7 +102,7 @@ int seeded_template(const uint8_t* dict, size_t dict_len, lzf_u32_table* host_ta
     return rc;
 }
 
-uint64_t g_host_block_hashes = 0, g_reader_device_hashes = 0;
+std::atomic<uint64_t> g_host_block_hashes{0}, g_reader_device_hashes{0};
 size_t g_budget = 0;     // lzf_frame_set_memory_budget (0: half of the free device memory)
 
 // One block of a frame as the scan finds it (decompress.rs:217-235).
@@ -405,7 +406,8 @@ struct Trace {
 // device scratch slots of the frame drivers (Staging::device)
 enum { S_IN = 0, S_OUT, S_PACK, S_JOBS, S_RES, S_LISTS, S_TABS, S_TABPTR, S_ADDS, S_TMPL, S_DICT, S_STEPS, S_STATE, S_HASH };
 
-lzf_frame_stats g_stats = {};
+// counters of lzf_frame_get_stats (calls on different devices run concurrently)
+struct { std::atomic<uint64_t> calls{0}, device_block_hashes{0}, device_content_hashes{0}, host_content_hashes{0}; } g_stats;
 
 // n small host arrays -> one device slot, one copy: ptr(i) is array i on the device
 struct Lists {
@@ -432,9 +434,10 @@ extern "C" {
 void lzf_frame_get_stats(lzf_frame_stats* st) {
     Staging& sg = Staging::get();
     std::lock_guard<std::mutex> g(sg.lock());
-    *st = g_stats;
+    memset(st, 0, sizeof *st);
+    st->calls = g_stats.calls; st->device_content_hashes = g_stats.device_content_hashes; st->host_content_hashes = g_stats.host_content_hashes;
     st->host_block_hashes = g_host_block_hashes;
-    st->device_block_hashes += g_reader_device_hashes;
+    st->device_block_hashes = g_stats.device_block_hashes + g_reader_device_hashes;
     st->h2d_copies = sg.counters.h2d_copies; st->d2h_copies = sg.counters.d2h_copies;
     st->h2d_bytes = sg.counters.h2d_bytes; st->d2h_bytes = sg.counters.d2h_bytes;
     st->pinned_bytes = sg.pinned_capacity();

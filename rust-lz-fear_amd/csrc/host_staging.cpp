@@ -78,7 +78,17 @@ struct Staging::Pool {
     }
 };
 
-Staging& Staging::get() { static Staging* s = new Staging; return *s; }      // (never destroyed: no HIP calls at exit)
+// One instance per device (the calling thread's current device picks it), created on first use and never destroyed (no HIP
+// calls at exit): a process that drives several GPUs keeps a slab and scratch on each.
+Staging& Staging::get() {
+    static std::mutex m;
+    static Staging* inst[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipGetLastError(); dev = 0; }
+    std::lock_guard<std::mutex> g(m);
+    if (!inst[dev]) inst[dev] = new Staging;
+    return *inst[dev];
+}
 
 Staging::Pool* Staging::pool() {
     unsigned want = want_threads_;

@@ -7,7 +7,7 @@
 //     thread issues one asynchronous H2D / D2H copy per finished piece — the memcpy of piece k + 1 overlaps the DMA of k;
 //   * device scratch is kept between calls as well (hipMalloc / hipFree of gigabytes cost more than the kernels).
 // Every HIP call is made by the calling thread (its current device is the one used); workers only run memcpy.
-// One call at a time per process uses the slab: the entry points take Staging::lock().
+// One instance per device; one call at a time per device uses its slab: the entry points take Staging::lock().
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstddef>
