@@ -56,6 +56,22 @@ uint32_t cu_count() {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// The batch calls take their scratch (launch orders, cost probes) from the stream-ordered pool.  By default the pool hands its
+// memory back at every synchronisation point, so the next call allocates from the device again — which waits for whatever is
+// running.  Keep what the pool has: a later hipMallocAsync on the same stream re-uses it without touching the device.
+void keep_pool_memory() {
+    static thread_local int done_for = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev == done_for) return;
+    hipMemPool_t pool = nullptr;
+    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+        uint64_t keep = ~0ull;
+        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+    }
+    (void)hipGetLastError();
+    done_for = dev;
+}
+
 // the three kernels of the product dispatch (lzf_decompress_batch)
 constexpr auto k_paired48 = lzf::lzf_decompress_paired_kernel<4096, 48, 640>;
 constexpr auto k_paired24 = lzf::lzf_decompress_paired_kernel<4096, 24, 384>;
@@ -86,6 +102,7 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
     int rc = ensure_device();
     if (rc < 0) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    keep_pool_memory();
     if ((table_kinds & (LZF_KINDS_U32 | LZF_KINDS_U16)) == 0) table_kinds |= LZF_KINDS_U32 | LZF_KINDS_U16;
     // U32 jobs with a fresh or read-only template table go to the compact-table kernel (18 instead of 10 waves per CU), the
     // others to the general kernel; which is which is in the job array, i.e. in HBM, so both are launched (a wave of the
@@ -137,6 +154,7 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
     int rc = ensure_device();
     if (rc < 0) return rc;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    keep_pool_memory();
     uint32_t use_order = 1u;
     bool perm_ok = true;
 #ifdef LZF_ANALYSIS

@@ -404,7 +404,8 @@ struct Trace {
 #endif
 
 // device scratch slots of the frame drivers (Staging::device)
-enum { S_IN = 0, S_OUT, S_PACK, S_JOBS, S_RES, S_LISTS, S_TABS, S_TABPTR, S_ADDS, S_TMPL, S_DICT, S_STEPS, S_STATE, S_HASH };
+enum { S_IN = 0, S_OUT, S_PACK, S_JOBS, S_RES, S_LISTS, S_TABS, S_TABPTR, S_ADDS, S_TMPL, S_DICT, S_STEPS, S_STATE, S_HASH, S_LISTS_G /* .. + 7: per group */, S_IN_G = S_LISTS_G + 8, S_OUT_G = S_IN_G + 8, S_COUNT = S_OUT_G + 8 };
+static_assert(S_COUNT <= Staging::kSlots, "device scratch slots");
 
 // counters of lzf_frame_get_stats (calls on different devices run concurrently)
 struct { std::atomic<uint64_t> calls{0}, device_block_hashes{0}, device_content_hashes{0}, host_content_hashes{0}; } g_stats;
@@ -468,14 +469,15 @@ int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint
     const bool bsum = s->block_checksums != 0, csum = s->content_checksum != 0;
 
     // ---- layout: input slab, output slab (cap n per block, :242), job list ordered by step
-    struct Fr { size_t nb, in_off, job0, data_off; };                          // data_off: the frame's own bytes in the slab (not per_block_prefix)
+    struct Fr { size_t nb, in_off, job0, data_off, out0; uint32_t grp; };      // data_off: the frame's own bytes in the slab (not per_block_prefix); out0: its first output slot
     std::vector<Fr> fr(n_frames);
     size_t in_total = 0, out_total = 0, n_jobs = 0, max_nb = 0, pack_bound = 0;
     for (uint32_t f = 0; f < n_frames; ++f) {
         fr[f].nb = status[f] == LZF_OK ? (in_len[f] + bs - 1) / bs : 0;
         fr[f].in_off = in_total; fr[f].data_off = in_total + (per_block_prefix ? 0 : dict_len);
+        fr[f].job0 = n_jobs; fr[f].out0 = pack_bound; fr[f].grp = 0;           // (job0: independent mode, where jobs are in frame order)
         if (fr[f].nb) in_total = up256(in_total + (per_block_prefix ? fr[f].nb * dict_len : dict_len) + in_len[f]);
-        if (fr[f].nb) pack_bound = up256(pack_bound + in_len[f]);
+        if (fr[f].nb) pack_bound += in_len[f];                                  // every block's output slot is as long as the block (:242)
         n_jobs += fr[f].nb; if (fr[f].nb > max_nb) max_nb = fr[f].nb;
     }
     if (n_jobs == 0) {                                                          // only empty inputs: header + EndMark each
@@ -497,9 +499,36 @@ int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint
     std::vector<uint32_t> job_frame(n_jobs), job_block(n_jobs);
     std::vector<size_t> job_out_off(n_jobs);
     std::vector<size_t> step_off;                                               // linked: jobs of step k are [step_off[k], step_off[k+1])
-    uint8_t* const din = static_cast<uint8_t*>(sg.device(S_IN, in_total));
-    if (!din) return LZF_E_HIP;
-    std::vector<Seg> up;                                                        // host -> slab
+    // ---- sub-groups of whole frames.  A call with enough independent blocks to fill the chip several times over travels in up to
+    //      kPipe groups, one behind the other on the same stream: group g compresses while g + 1 is still on its way in and
+    //      g - 1 is on its way out.  (Linked streams, and calls too small to keep the chip busy per group, are one group.)
+    //      Every group has its own input and output allocation: the runtime orders a copy behind the last launch that touches
+    //      the same allocation, whatever the stream, so with one buffer for all no copy would overlap a kernel.
+    constexpr uint32_t kPipe = 8, kFill = 4608;                                 // kFill: one-wave jobs the chip holds at once (18 per CU)
+    // (groups of at most kFill jobs where kPipe groups allow it: such a launch needs no cost-ordered launch list, whose scratch
+    //  allocation would wait for the group before it)
+    const uint32_t n_groups = indep && n_jobs >= 2u * kFill ? ((n_jobs + kFill - 1) / kFill < kPipe ? (uint32_t)((n_jobs + kFill - 1) / kFill) : kPipe) : 1u;
+    std::vector<uint32_t> gend(n_groups, n_frames);                             // group g = frames [gend[g-1], gend[g])
+    for (uint32_t g = 0, f = 0; g + 1 < n_groups; ++g) {
+        while (f < n_frames && (fr[f].nb == 0 || fr[f].job0 + fr[f].nb < n_jobs * (size_t)(g + 1) / n_groups)) ++f;
+        gend[g] = f < n_frames ? ++f : n_frames;
+    }
+    // the layout is one address space for inputs [0, in_total) and one for output slots [0, pack_bound); group g's part of each is
+    // backed by its own allocation, addressed through a base biased by where the part starts
+    std::vector<uintptr_t> din_b(n_groups), dout_b(n_groups);
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint32_t fa = g ? gend[g - 1] : 0, fb = gend[g];
+        const size_t ia = fa < n_frames ? fr[fa].in_off : in_total, ib = fb < n_frames ? fr[fb].in_off : in_total;
+        const size_t oa = fa < n_frames ? fr[fa].out0 : pack_bound, ob = fb < n_frames ? fr[fb].out0 : pack_bound;
+        void* const di = sg.device(S_IN_G + (int)g, ib - ia);
+        void* const dob = sg.device(S_OUT_G + (int)g, ob - oa);
+        if (!di || !dob) return LZF_E_HIP;
+        din_b[g] = reinterpret_cast<uintptr_t>(di) - ia; dout_b[g] = reinterpret_cast<uintptr_t>(dob) - oa;
+        for (uint32_t f = fa; f < fb; ++f) fr[f].grp = g;
+    }
+    auto din_at = [&](uint32_t f, size_t off) { return reinterpret_cast<uint8_t*>(din_b[fr[f].grp] + off); };   // off: offset in the input address space
+    std::vector<Seg> up;                                                        // host -> slab, in frame order
+    std::vector<size_t> up_first(n_frames, 0);                                  // independent mode: frame f's pieces start at up[up_first[f]]
     auto seg = [&](size_t off, const uint8_t* p, size_t n) { if (n) up.push_back({off, const_cast<uint8_t*>(p), n}); };
 
     lzf_u32_table tmpl;
@@ -522,7 +551,7 @@ int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint
     size_t jn = 0;
     if (indep) {
         for (uint32_t f = 0; f < n_frames; ++f) {
-            fr[f].job0 = jn;
+            fr[f].job0 = jn; up_first[f] = up.size();
             size_t w = fr[f].in_off;
             if (fr[f].nb && !per_block_prefix) seg(w, in[f], in_len[f]);
             for (size_t i = 0; i < fr[f].nb; ++i, ++jn) {
@@ -531,8 +560,8 @@ int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint
                 memset(&j, 0, sizeof j);
                 if (per_block_prefix) {
                     seg(w, dict, dict_len); seg(w + dict_len, in[f] + off, n);
-                    j.input = din + w; j.input_len = dict_len + n; j.cursor = dict_len; w += dict_len + n;
-                } else { j.input = din + fr[f].in_off + off; j.input_len = n; j.cursor = 0; }
+                    j.input = din_at(f, w); j.input_len = dict_len + n; j.cursor = dict_len; w += dict_len + n;
+                } else { j.input = din_at(f, fr[f].in_off + off); j.input_len = n; j.cursor = 0; }
                 j.out_cap = n; j.table_kind = LZF_TABLE_U32;                   // :242, :202
                 if (dict_len >= 8) { j.table = d_tmpl; j.flags = LZF_CJOB_TABLE_READONLY; }       // :220,:270 template.clone()
                 job_frame[jn] = f; job_block[jn] = (uint32_t)i; job_out_off[jn] = out_total; out_total += n;
@@ -553,7 +582,7 @@ int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint
                 const size_t off = k * bs, n = in_len[f] - off < bs ? in_len[f] - off : bs;
                 lzf_compress_job& j = jobs[jn];
                 memset(&j, 0, sizeof j);
-                j.input = din + fr[f].in_off + ls[f].lo; j.input_len = ls[f].len + n; j.cursor = ls[f].len;   // :222,:243
+                j.input = din_at(f, fr[f].in_off + ls[f].lo); j.input_len = ls[f].len + n; j.cursor = ls[f].len;   // :222,:243
                 j.out_cap = n; j.table_kind = LZF_TABLE_U32;
                 j.table = d_tabs + lf_index[f];
                 h_tabptr[jn] = j.table; h_adds[jn] = pending_add[f];           // applied before this step
@@ -566,15 +595,17 @@ int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint
         }
         step_off.push_back(jn);
     }
-    uint8_t* const dout = static_cast<uint8_t*>(sg.device(S_OUT, out_total));
     lzf_compress_job* const d_jobs = static_cast<lzf_compress_job*>(sg.device(S_JOBS, sizeof(lzf_compress_job) * n_jobs));
     lzf_job_result* const d_res = static_cast<lzf_job_result*>(sg.device(S_RES, sizeof(lzf_job_result) * n_jobs));
-    if (!dout || !d_jobs || !d_res) return LZF_E_HIP;
-    for (size_t q = 0; q < n_jobs; ++q) jobs[q].out = dout + job_out_off[q];
-    // ---- inputs up (pieces, asynchronous), small arrays behind them
+    if (!d_jobs || !d_res) return LZF_E_HIP;
+    for (size_t q = 0; q < n_jobs; ++q) jobs[q].out = reinterpret_cast<uint8_t*>(dout_b[fr[job_frame[q]].grp] + job_out_off[q]);
+    // results come back through the pinned mailbox: [block results | content hashes | block checksums]
+    const size_t mb_res = 0, mb_chash = up256(sizeof(lzf_job_result) * n_jobs), mb_sums = mb_chash + up256(sizeof(uint32_t) * n_frames);
+    uint8_t* const mbox = sg.mailbox(mb_sums + sizeof(uint32_t) * n_jobs);
+    if (!mbox) return LZF_E_HIP;
+    const lzf_job_result* const res = reinterpret_cast<const lzf_job_result*>(mbox + mb_res);
     TRACE("c: layout + scratch");
-    HIPOK(sg.upload(up, in_total, din));
-    TRACE("c: upload issued");
+    // ---- in: small arrays first, then group after group: its bytes (pieces, asynchronous), its launches, its results
     HIPOK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(lzf_compress_job) * n_jobs, hipMemcpyHostToDevice, cs));
     void** d_tabptr = nullptr; uint64_t* d_adds = nullptr;
     std::vector<lzf_u32_table> h_tabs;
@@ -587,21 +618,42 @@ int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint
         HIPOK(hipMemcpyAsync(d_tabptr, h_tabptr.data(), sizeof(void*) * n_jobs, hipMemcpyHostToDevice, cs));
         HIPOK(hipMemcpyAsync(d_adds, h_adds.data(), sizeof(uint64_t) * n_jobs, hipMemcpyHostToDevice, cs));
     }
-    HIPOK(sg.join_copies(cs));
-    // ---- launches: no host round trip between the steps
-    for (size_t k = 0; k + 1 < step_off.size(); ++k) {
-        const size_t a = step_off[k], cnt = step_off[k + 1] - a;
-        if (!cnt) continue;
-        if (!indep && k > 0) RCOK(lzf_table_offset_batch(d_tabptr + a, d_adds + a, (uint32_t)cnt, LZF_TABLE_U32, cs));
-        RCOK(lzf_compress_batch(d_jobs + a, d_res + a, (uint32_t)cnt, indep ? (LZF_KINDS_U32 | LZF_KINDS_U32_FRESH_ONLY) : LZF_KINDS_U32, cs));
+    struct Events {                                                             // one "group g is compressed" event each
+        std::vector<hipEvent_t> e;
+        ~Events() { for (hipEvent_t x : e) if (x) (void)hipEventDestroy(x); }
+    } done;
+    done.e.assign(n_groups, nullptr);
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        const uint32_t fa = g ? gend[g - 1] : 0, fb = gend[g];
+        const size_t ua = fa < n_frames ? up_first[fa] : up.size(), ub = fb < n_frames ? up_first[fb] : up.size();
+        HIPOK(sg.upload(std::vector<Seg>(up.begin() + ua, up.begin() + ub), in_total, reinterpret_cast<uint8_t*>(din_b[g])));
+        TRACE("c:   group upload");
+        HIPOK(sg.join_copies(cs));
+        TRACE("c:     join");
+        if (indep) {
+            size_t a = n_jobs, e = 0;
+            for (uint32_t f = fa; f < fb; ++f) if (fr[f].nb) { if (fr[f].job0 < a) a = fr[f].job0; if (fr[f].job0 + fr[f].nb > e) e = fr[f].job0 + fr[f].nb; }
+            if (e > a) {
+                RCOK(lzf_compress_batch(d_jobs + a, d_res + a, (uint32_t)(e - a), LZF_KINDS_U32 | LZF_KINDS_U32_FRESH_ONLY, cs));
+                TRACE("c:     batch call");
+                HIPOK(hipMemcpyAsync(mbox + mb_res + sizeof(lzf_job_result) * a, d_res + a, sizeof(lzf_job_result) * (e - a), hipMemcpyDeviceToHost, cs));
+                TRACE("c:     result copy");
+            }
+        } else {
+            for (size_t k = 0; k + 1 < step_off.size(); ++k) {                 // no host round trip between the steps
+                const size_t a = step_off[k], cnt = step_off[k + 1] - a;
+                if (!cnt) continue;
+                if (k > 0) RCOK(lzf_table_offset_batch(d_tabptr + a, d_adds + a, (uint32_t)cnt, LZF_TABLE_U32, cs));
+                RCOK(lzf_compress_batch(d_jobs + a, d_res + a, (uint32_t)cnt, LZF_KINDS_U32, cs));
+            }
+            HIPOK(hipMemcpyAsync(mbox + mb_res, d_res, sizeof(lzf_job_result) * n_jobs, hipMemcpyDeviceToHost, cs));
+        }
+        HIPOK(hipEventCreateWithFlags(&done.e[g], hipEventDisableTiming));
+        HIPOK(hipEventRecord(done.e[g], cs));
+        TRACE("c:   group launch");
     }
-    // results come back through the pinned mailbox: [block results | content hashes | block checksums]
-    const size_t mb_res = 0, mb_chash = up256(sizeof(lzf_job_result) * n_jobs), mb_sums = mb_chash + up256(sizeof(uint32_t) * n_frames);
-    uint8_t* const mbox = sg.mailbox(mb_sums + sizeof(uint32_t) * n_jobs);
-    if (!mbox) return LZF_E_HIP;
-    const lzf_job_result* const res = reinterpret_cast<const lzf_job_result*>(mbox + mb_res);
-    HIPOK(hipMemcpyAsync(mbox + mb_res, d_res, sizeof(lzf_job_result) * n_jobs, hipMemcpyDeviceToHost, cs));
-    // ---- content checksums (:233-235): one device chain per frame on the second stream while the blocks compress;
+    TRACE("c: uploads + launches issued");
+    // ---- content checksums (:233-235): one device chain per frame on the checksum stream while the blocks compress;
     //      long frames (and dict ++ block layouts, where the frame is not contiguous in the slab) on the workers
     std::vector<uint32_t> content(n_frames, 0);
     std::vector<uint32_t> dev_hash_frames, host_hash_frames;
@@ -614,7 +666,7 @@ int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint
     const uint32_t* const chash = reinterpret_cast<const uint32_t*>(mbox + mb_chash);
     if (!dev_hash_frames.empty()) {
         std::vector<const uint8_t*> p; std::vector<uint64_t> n;
-        for (uint32_t f : dev_hash_frames) { p.push_back(din + fr[f].data_off); n.push_back(in_len[f]); }
+        for (uint32_t f : dev_hash_frames) { p.push_back(din_at(f, fr[f].data_off)); n.push_back(in_len[f]); }
         const size_t ip = hl.add(p.data(), p.size() * sizeof p[0]), il = hl.add(n.data(), n.size() * sizeof n[0]), io = hl.add(nullptr, p.size() * sizeof(uint32_t));
         HIPOK(sg.join_copies(hs));
         RCOK(hl.upload(sg, S_HASH, hs));
@@ -629,70 +681,70 @@ int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint
         host_hashes(sg, p, n, h);
         for (size_t i = 0; i < h.size(); ++i) content[host_hash_frames[i]] = h[i];
     }
-    TRACE("c: launches + host hashes");
-    HIPOK(hipStreamSynchronize(cs));                                            // block results are here
-    TRACE("c: kernels done");
-    // ---- frame layout (:244-263, :277-281): header and length words straight into the caller's buffer, payloads packed
-    //      on the device in frame order (stored blocks, :250-255, from the input slab), checksums over the packed payloads
+    TRACE("c: content hashes issued / host hashes");
+    // ---- out, group after group (:244-263, :277-281): header and length words straight into the caller's buffer, every
+    //      compressed payload from its output slot through the slab to its place in the frame, stored blocks (:250-255)
+    //      from the caller's own input, block checksums over the device copies of both
     std::vector<std::vector<size_t>> frame_jobs(n_frames);
     for (size_t q = 0; q < n_jobs; ++q) { auto& v = frame_jobs[job_frame[q]]; if (v.size() <= job_block[q]) v.resize(job_block[q] + 1); v[job_block[q]] = q; }
-    std::vector<const uint8_t*> r_src; std::vector<uint8_t*> r_dst; std::vector<uint64_t> r_len;      // device copies
-    std::vector<Seg> down;                                                      // packed slab -> caller
     struct Patch { uint8_t* at; size_t hash_index; };
     std::vector<Patch> sum_at;                                                  // where block checksum i goes
+    struct HostCopy { uint8_t* dst; const uint8_t* src; size_t n; };
+    std::vector<HostCopy> stored_copies;
     std::vector<uint8_t*> content_at(n_frames, nullptr);
-    size_t pk_total = 0; uint64_t r_max = 0;
-    std::vector<size_t> pk_pos;                                                 // packed offset of each range (r_dst is filled in once the slab exists)
-    for (uint32_t f = 0; f < n_frames; ++f) {
-        if (status[f] != LZF_OK) continue;
-        if (fr[f].nb == 0) { status[f] = lzf_frame_assemble(s, 0, nullptr, nullptr, nullptr, content[f], out[f], out_cap[f], &out_len[f]); continue; }   // an empty input: header + EndMark
-        const size_t nb = fr[f].nb;
-        int st = LZF_OK;
-        for (size_t i = 0; i < nb && st == LZF_OK; ++i) { const int bst = res[frame_jobs[f][i]].status; if (bst != LZF_OK && bst != LZF_OUTPUT_FULL) st = bst; }
-        if (st != LZF_OK) { status[f] = st; continue; }
-        size_t w = write_header(s, bd, out[f]);
-        for (size_t i = 0; i < nb; ++i) {
-            const size_t q = frame_jobs[f][i], off = i * bs, n = in_len[f] - off < bs ? in_len[f] - off : bs;
-            const bool stored = res[q].status == LZF_OUTPUT_FULL;                                     // :250-255
-            const uint32_t len = stored ? (uint32_t)n : (uint32_t)res[q].out_len;
-            wr32(out[f] + w, stored ? (len | INCOMPRESSIBLE) : len); w += 4;                           // :247,253
-            r_src.push_back(stored ? jobs[q].input + jobs[q].cursor : jobs[q].out); r_len.push_back(len); pk_pos.push_back(pk_total);
-            if (len > r_max) r_max = len;
-            down.push_back({pk_total, out[f] + w, len});                                              // :258
-            pk_total += len; w += len;
-            if (bsum) { sum_at.push_back({out[f] + w, r_src.size() - 1}); w += 4; }                   // :259-263
+    std::vector<Lists> sum_lists(n_groups);
+    size_t n_hashed = 0;
+    for (uint32_t g = 0; g < n_groups; ++g) {
+        HIPOK(hipEventSynchronize(done.e[g]));                                  // the group's block results are in the mailbox
+        if (g == 0) TRACE("c: first group compressed");
+        std::vector<Seg> down;
+        std::vector<const uint8_t*> h_ptr; std::vector<uint64_t> h_len;
+        const size_t hash0 = n_hashed;
+        for (uint32_t f = g ? gend[g - 1] : 0; f < gend[g]; ++f) {
+            if (status[f] != LZF_OK) continue;
+            if (fr[f].nb == 0) { status[f] = lzf_frame_assemble(s, 0, nullptr, nullptr, nullptr, content[f], out[f], out_cap[f], &out_len[f]); continue; }   // an empty input: header + EndMark
+            const size_t nb = fr[f].nb;
+            int st = LZF_OK;
+            for (size_t i = 0; i < nb && st == LZF_OK; ++i) { const int bst = res[frame_jobs[f][i]].status; if (bst != LZF_OK && bst != LZF_OUTPUT_FULL) st = bst; }
+            if (st != LZF_OK) { status[f] = st; continue; }
+            size_t w = write_header(s, bd, out[f]);
+            for (size_t i = 0; i < nb; ++i) {
+                const size_t q = frame_jobs[f][i], off = i * bs, n = in_len[f] - off < bs ? in_len[f] - off : bs;
+                const bool stored = res[q].status == LZF_OUTPUT_FULL;                                     // :250-255
+                const uint32_t len = stored ? (uint32_t)n : (uint32_t)res[q].out_len;
+                wr32(out[f] + w, stored ? (len | INCOMPRESSIBLE) : len); w += 4;                           // :247,253
+                if (stored) stored_copies.push_back({out[f] + w, in[f] + off, n});
+                else if (len) down.push_back({job_out_off[q], out[f] + w, len});                          // :258
+                w += len;
+                if (bsum) {                                                                                // :259-263
+                    h_ptr.push_back(stored ? jobs[q].input + jobs[q].cursor : jobs[q].out); h_len.push_back(len);
+                    sum_at.push_back({out[f] + w, n_hashed++}); w += 4;
+                }
+            }
+            wr32(out[f] + w, 0); w += 4;                                                                   // :277 EndMark
+            if (csum) { content_at[f] = out[f] + w; w += 4; }                                              // :279-281
+            out_len[f] = w;
         }
-        pk_total = up256(pk_total);
-        wr32(out[f] + w, 0); w += 4;                                                                   // :277 EndMark
-        if (csum) { content_at[f] = out[f] + w; w += 4; }                                              // :279-281
-        out_len[f] = w;
+        if (!h_ptr.empty()) {
+            Lists& rl = sum_lists[g];
+            const size_t ip = rl.add(h_ptr.data(), h_ptr.size() * sizeof h_ptr[0]), il = rl.add(h_len.data(), h_len.size() * sizeof h_len[0]), io = rl.add(nullptr, h_ptr.size() * sizeof(uint32_t));
+            HIPOK(hipStreamWaitEvent(hs, done.e[g], 0));
+            RCOK(rl.upload(sg, S_LISTS_G + (int)g, hs));
+            RCOK(lzf_xxh32_batch(rl.ptr<const uint8_t*>(ip), rl.ptr<uint64_t>(il), rl.ptr<uint32_t>(io), (uint32_t)h_ptr.size(), hs));
+            HIPOK(hipMemcpyAsync(mbox + mb_sums + sizeof(uint32_t) * hash0, rl.ptr<uint32_t>(io), h_ptr.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, hs));
+            g_stats.device_block_hashes += h_ptr.size();
+        }
+        TRACE("c:   group layout");
+        HIPOK(sg.download(down, out_total, reinterpret_cast<const uint8_t*>(dout_b[g]), nullptr, done.e[g]));          // (returns when the group's payloads are in place)
+        TRACE("c:   group download");
     }
-    const uint32_t* const sums = reinterpret_cast<const uint32_t*>(mbox + mb_sums);
-    if (!r_src.empty()) {
-        uint8_t* const dpack = static_cast<uint8_t*>(sg.device(S_PACK, pk_total));
-        if (!dpack) return LZF_E_HIP;
-        r_dst.resize(r_src.size());
-        for (size_t i = 0; i < r_src.size(); ++i) r_dst[i] = dpack + pk_pos[i];
-        Lists rl;
-        const size_t is = rl.add(r_src.data(), r_src.size() * sizeof r_src[0]), id = rl.add(r_dst.data(), r_dst.size() * sizeof r_dst[0]),
-                     il = rl.add(r_len.data(), r_len.size() * sizeof r_len[0]), io = rl.add(nullptr, r_src.size() * sizeof(uint32_t));
-        RCOK(rl.upload(sg, S_LISTS, cs));
-        RCOK(lzf_copy_ranges(rl.ptr<const uint8_t*>(is), rl.ptr<uint8_t*>(id), rl.ptr<uint64_t>(il), (uint32_t)r_src.size(), r_max, cs));
-        if (bsum) {
-            RCOK(lzf_xxh32_batch(rl.ptr<const uint8_t*>(id), rl.ptr<uint64_t>(il), rl.ptr<uint32_t>(io), (uint32_t)r_src.size(), cs));
-            g_stats.device_block_hashes += r_src.size();
-        }
-        TRACE("c: frame layout + pack issued");
-        if (bsum) HIPOK(hipMemcpyAsync(mbox + mb_sums, rl.ptr<uint32_t>(io), r_src.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, cs));
-        HIPOK(sg.download(down, pk_total, dpack, cs));                          // (returns when the payloads are in place)
-        TRACE("c: download");
-        if (bsum) {
-            HIPOK(hipStreamSynchronize(cs));
-            for (const Patch& pt : sum_at) wr32(pt.at, sums[pt.hash_index]);
-        }
-    }
+    TRACE("c: downloads");
+    sg.parallel_for(stored_copies.size(), [&](size_t i) { memcpy(stored_copies[i].dst, stored_copies[i].src, stored_copies[i].n); });
     HIPOK(hipStreamSynchronize(hs));
-    TRACE("c: content hashes");
+    HIPOK(hipStreamSynchronize(cs));
+    TRACE("c: checksums home");
+    const uint32_t* const sums = reinterpret_cast<const uint32_t*>(mbox + mb_sums);
+    for (const Patch& pt : sum_at) wr32(pt.at, sums[pt.hash_index]);
     for (size_t i = 0; i < dev_hash_frames.size(); ++i) content[dev_hash_frames[i]] = chash[i];
     for (uint32_t f = 0; f < n_frames; ++f) if (content_at[f]) wr32(content_at[f], content[f]);
     ++g_stats.calls;

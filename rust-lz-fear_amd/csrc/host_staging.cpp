@@ -219,17 +219,18 @@ hipError_t Staging::join_copies(hipStream_t waiter) {
     return hipSuccess;
 }
 
-hipError_t Staging::download(const std::vector<Seg>& segs, size_t slab_bytes, const uint8_t* d_base, hipStream_t before) {
+hipError_t Staging::download(const std::vector<Seg>& segs, size_t slab_bytes, const uint8_t* d_base, hipStream_t before, hipEvent_t ready) {
     size_t total = 0;
     for (const Seg& s : segs) total += s.len;
-    hipStream_t c1 = stream(1), c2 = stream(2);
+    hipStream_t c1 = stream(4), c2 = stream(5);      // the way back has its own pair of streams: it overlaps uploads still in flight
     if (!c1 || !c2) return hipErrorUnknown;
     if (before) {
         hipEvent_t e0 = event(0);
         if (!e0) return hipErrorUnknown;
         TRY(hipEventRecord(e0, before)); TRY(hipStreamWaitEvent(c1, e0, 0)); TRY(hipStreamWaitEvent(c2, e0, 0));
     }
-    if (!total) { if (before) TRY(hipStreamSynchronize(before)); return hipSuccess; }
+    if (ready) { TRY(hipStreamWaitEvent(c1, ready, 0)); TRY(hipStreamWaitEvent(c2, ready, 0)); }
+    if (!total) { if (before) TRY(hipStreamSynchronize(before)); if (ready) TRY(hipEventSynchronize(ready)); return hipSuccess; }
     uint8_t* pin = pinned(slab_bytes);
     if (!pin) return hipErrorOutOfMemory;
     if (total <= kInline) {

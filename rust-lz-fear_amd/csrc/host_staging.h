@@ -30,8 +30,8 @@ public:
     uint8_t* pinned(size_t bytes);                     // the pinned slab, at least `bytes` long
     uint8_t* mailbox(size_t bytes);                    // a second, small pinned buffer for results that come back asynchronously
     void* device(int slot, size_t bytes);              // device scratch slot (0..kSlots-1), at least `bytes` long
-    static constexpr int kSlots = 16;
-    hipStream_t stream(int i);                         // 0: compute, 1..2: copy engines, 3: checksums (non-blocking streams)
+    static constexpr int kSlots = 40;
+    hipStream_t stream(int i);                         // 0: compute, 1..2: copies in, 3: checksums, 4..5: copies out (non-blocking streams)
     void release();                                    // give everything back (lzf_host_release_scratch)
     void set_threads(unsigned n);                      // worker threads for the next calls (0 = default)
     size_t pinned_capacity() const { return pin_cap_; }
@@ -41,8 +41,9 @@ public:
     // (join_copies makes another stream wait for them).  The slab range in use is [0, slab_bytes).
     hipError_t upload(const std::vector<Seg>& segs, size_t slab_bytes, uint8_t* d_base);
     hipError_t join_copies(hipStream_t waiter);        // `waiter` waits for everything issued on the copy streams so far
-    // device -> slab -> host: waits for `before` (may be null), then the mirror image; returns when every byte is in place.
-    hipError_t download(const std::vector<Seg>& segs, size_t slab_bytes, const uint8_t* d_base, hipStream_t before);
+    // device -> slab -> host: waits for `before` (a stream, may be null) and / or `ready` (an event already recorded, may be
+    // null), then the mirror image; returns when every byte is in place.
+    hipError_t download(const std::vector<Seg>& segs, size_t slab_bytes, const uint8_t* d_base, hipStream_t before, hipEvent_t ready = nullptr);
     // fn(i) for i in [0, n) on the workers (and the calling thread); returns when all are done
     void parallel_for(size_t n, const std::function<void(size_t)>& fn);
 
@@ -55,7 +56,7 @@ private:
     uint8_t* pin_ = nullptr; size_t pin_cap_ = 0;
     uint8_t* mail_ = nullptr; size_t mail_cap_ = 0;
     void* dev_[kSlots] = {}; size_t dev_cap_[kSlots] = {};
-    hipStream_t streams_[4] = {};
+    hipStream_t streams_[6] = {};
     std::vector<hipEvent_t> events_;
 public:
     struct Counters { uint64_t h2d_copies, d2h_copies, h2d_bytes, d2h_bytes; } counters = {0, 0, 0, 0};

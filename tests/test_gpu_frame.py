@@ -522,3 +522,30 @@ def test_examples_dolz4_delz4_round_trip(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "delz4.py"), str(lz), str(back)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert back.read_bytes() == data
+
+
+@pytest.mark.parametrize("kw", [dict(block_size=64 << 10, block_checksums=True), dict(block_size=64 << 10, dictionary=synth.gen_text_zipf(21, 5000).tobytes(), dictionary_id=5)])
+def test_compress_many_in_pipelined_groups_is_still_the_reference_frame(kw):
+    """More than 9216 independent blocks in one lzf_frame_compress_many call travel in several groups (own device buffers,
+    upload / compress / download overlapping): every frame must still be the oracle's frame, checksums included, with an empty
+    input, a stored-block input and ragged sizes among them; and the frames decode back in one call."""
+    from rust_lz_fear_amd import ffi
+    mix = synth.silesia_mix(0, 200 << 20)
+    sizes = [27 << 20] * 10 + [0, (27 << 20) + 12345, 5, (26 << 20) + 65536 * 3 + 1] + [28 << 20] * 9
+    datas, pos = [], 0
+    for i, n in enumerate(sizes):
+        datas.append(mix[pos % (mix.size - n): pos % (mix.size - n) + n].tobytes() if n else b""); pos += n + 777_777
+    datas.append(vectors.rng_bytes(17, 3 << 20))
+    assert sum((len(d) + 65535) // 65536 for d in datas) > 9216
+    g, okw = settings_pair(**kw)
+    s0 = ffi.frame_stats()
+    frames = g.compress_many(datas)
+    s1 = ffi.frame_stats()
+    es = o.make_settings(**okw)
+    for d, f in zip(datas, frames):
+        assert f == o.frame_compress(d, es)[1], len(d)
+    if kw.get("block_checksums"):
+        assert s1["host_block_hashes"] == s0["host_block_hashes"]
+        assert s1["device_block_hashes"] - s0["device_block_hashes"] == sum((len(d) + 65535) // 65536 for d in datas)
+    back = framed.decompress_frames(frames, dictionary=kw.get("dictionary", b""), caps=[len(d) + 64 for d in datas])
+    assert back == [(0, d) for d in datas]
