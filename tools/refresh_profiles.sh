@@ -6,7 +6,7 @@
 #                                               as the default run — counter collection at 240 copies does not finish) for HBM traffic
 #   gpurun_out/r02/hbm_traffic.json            the two passes as the file bench.py reads (copy to profiles/r02_hbm_traffic.json)
 #   gpurun_out/r02/bench_config4.json          python bench.py --workload config4
-#   gpurun_out/r02/bench_48distinct.json, bench_48rotated.json   seed-sensitivity check at equal size: 48 copies with 48 seeds vs 1 seed
+#   gpurun_out/r02/bench_240x48.json, bench_240x1.json   seed-sensitivity check at full size: 240 copies from 48 seeds / from 1 seed
 set -u
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; rm -rf $O; mkdir -p $O
 cd $R && timeout 1500 python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log > $O/bench_default.json
@@ -50,8 +50,9 @@ for which, needle, jobs in (("decompress", dk, line["kernel_only"]["blocks_per_g
 json.dump(out, open(os.path.join(O, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
 PY
-cd $R && timeout 900 python bench.py --workload config4 --no-cpu > $O/bench_config4.log 2>&1; tail -1 $O/bench_config4.log > $O/bench_config4.json
-# seed sensitivity at equal size (2448 blocks): every copy with its own seed vs one seed rotated + XOR-ed
-cd $R && timeout 900 python bench.py --copies 48 --distinct 48 --no-cpu --no-e2e > $O/bench_48distinct.log 2>&1; tail -1 $O/bench_48distinct.log > $O/bench_48distinct.json
-cd $R && timeout 900 python bench.py --copies 48 --distinct 1 --no-cpu --no-e2e > $O/bench_48rotated.log 2>&1; tail -1 $O/bench_48rotated.log > $O/bench_48rotated.json
-cut -c1-900 $O/bench_default.json; head -12 $O/kernel_stats.txt; cat $O/pmc_FETCH_SIZE.txt $O/pmc_WRITE_SIZE.txt; cut -c1-400 $O/bench_config4.json; cut -c1-300 $O/bench_48distinct.json; cut -c1-300 $O/bench_48rotated.json
+cd $R && timeout 900 python bench.py --workload config4 > $O/bench_config4.log 2>&1; tail -1 $O/bench_config4.log > $O/bench_config4.json
+# seed sensitivity at full size: 48 seeds and 1 seed against the default 12 (240 seeds: `--distinct 240`, three minutes of generation,
+# run once by hand: profiles/r02_bench_240x240distinct.json)
+cd $R && timeout 900 python bench.py --copies 240 --distinct 48 --no-cpu --no-e2e > $O/bench_240x48.log 2>&1; tail -1 $O/bench_240x48.log > $O/bench_240x48.json
+cd $R && timeout 900 python bench.py --copies 240 --distinct 1 --no-cpu --no-e2e > $O/bench_240x1.log 2>&1; tail -1 $O/bench_240x1.log > $O/bench_240x1.json
+cut -c1-900 $O/bench_default.json; head -12 $O/kernel_stats.txt; cat $O/pmc_FETCH_SIZE.txt $O/pmc_WRITE_SIZE.txt; cut -c1-400 $O/bench_config4.json; cut -c1-300 $O/bench_240x48.json; cut -c1-300 $O/bench_240x1.json
