@@ -51,7 +51,9 @@ __global__ void lzf_decompress_paired_kernel(const lzf_decompress_job* __restric
 #define LZF_PAIRED_VARIANTS(X) \
     X(paired16, 4096, 16, 256) \
     X(paired24, 4096, 24, 384) \
-    X(paired48, 4096, 48, 640)
+    X(paired48, 4096, 48, 640) \
+    X(paired128, 4096, 128, 1280) \
+    X(paired256, 4096, 256, 2048)
 #else
 #define LZF_PAIRED_VARIANTS(X) \
     X(paired24, 4096, 24, 384) \

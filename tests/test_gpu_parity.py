@@ -165,7 +165,7 @@ def _analysis_env(**kw):
     return dict(os.environ, LZF_LIB_PATH=path, **kw)
 
 
-@pytest.mark.parametrize("variant", ["auto", "wave", "staged16", "staged32", "direct4w", "win512", "win1024", "paired16", "paired24", "paired48",
+@pytest.mark.parametrize("variant", ["auto", "wave", "staged16", "staged32", "direct4w", "win512", "win1024", "paired16", "paired24", "paired48", "paired256",
                                      "walk64", "v4t24", "v5s512", "v6l256", "ordered"])
 def test_every_decompress_kernel_generation(variant):
     """Every kernel generation kept in the analysis library (and every ring/region geometry) implements the same contract.
