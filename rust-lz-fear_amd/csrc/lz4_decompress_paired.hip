@@ -44,6 +44,9 @@ __global__ __launch_bounds__(128) void lzf_decompress_paired_kernel(
 
     int status = LZF_OK;
     uint32_t o = 0;
+#ifdef LZF_DBG_PHASE_SEL
+    long long ph_acc_out = 0;
+#endif
     if (job.input_len >= kMaxPosB || job.out_existing_len >= kMaxPosB || job.prefix_len >= kMaxPosB || job.out_existing_len > job.out_cap) {
         status = LZF_CONTRACT;                         // (uniform over the workgroup: no barrier is reached)
     } else {
@@ -82,7 +85,13 @@ __global__ __launch_bounds__(128) void lzf_decompress_paired_kernel(
         };
 
 
+#ifdef LZF_DBG_PHASE_SEL   // analysis: cycles the copier spends in section LZF_DBG_PHASE_SEL of its batch loop (section i ends at PHASE(i);
+                           // 0 = between batches: loop control, chunk hand-over, waiting for the parser) -> results[].reserved
+        long long ph_t = clock64(), ph_acc = 0;
+#define PHASE(i) do { const long long tn__ = clock64(); if ((i) == LZF_DBG_PHASE_SEL) ph_acc += tn__ - ph_t; ph_t = tn__; } while (0)
+#else
 #define PHASE(i) do { } while (0)
+#endif
         if (threadIdx.x == 0) ctl_stop = 0;
         __syncthreads();
         if (role == 0u) {
@@ -178,13 +187,20 @@ __global__ __launch_bounds__(128) void lzf_decompress_paired_kernel(
                 if (status != LZF_OK && lane == 0u) *(volatile int*)&ctl_stop = 1;
             }
         }
+#ifdef LZF_DBG_PHASE_SEL
+        ph_acc_out = ph_acc;
+#endif
 #undef PHASE
 #undef RIDX
     }
     if (role == 1u && lane == 0u) {
         results[jid].out_len = o;
         results[jid].status = status;
+#ifdef LZF_DBG_PHASE_SEL
+        results[jid].reserved = (uint32_t)(ph_acc_out >> 10);
+#else
         results[jid].reserved = (uint32_t)((clock64() - t_start) >> 10);   // diagnostic: shader kilo-cycles spent on this job
+#endif
     }
 }
 
