@@ -47,6 +47,9 @@ __global__ __launch_bounds__(128) void lzf_decompress_paired_kernel(
 #ifdef LZF_DBG_PHASE_SEL
     long long ph_acc_out = 0;
 #endif
+#ifdef LZF_DBG_ROUNDS
+    uint32_t dbg_rounds = 0, dbg_batches = 0;
+#endif
     if (job.input_len >= kMaxPosB || job.out_existing_len >= kMaxPosB || job.prefix_len >= kMaxPosB || job.out_existing_len > job.out_cap) {
         status = LZF_CONTRACT;                         // (uniform over the workgroup: no barrier is reached)
     } else {
@@ -180,7 +183,9 @@ __global__ __launch_bounds__(128) void lzf_decompress_paired_kernel(
 
 #define LZF_TOKEN_AT(i) (toks[(i)] & 0xFFFFu)
 #define LZF_TOKEN_WORD(i) toks[(i)]
+#define LZF_DBG_ROUNDS_HERE
 #include "lz4_decompress_batch_phase.inc"
+#undef LZF_DBG_ROUNDS_HERE
 #undef LZF_TOKEN_WORD
 #undef LZF_TOKEN_AT
                 if (status == LZF_OK && cerr != LZF_OK) status = cerr;
@@ -198,6 +203,8 @@ __global__ __launch_bounds__(128) void lzf_decompress_paired_kernel(
         results[jid].status = status;
 #ifdef LZF_DBG_PHASE_SEL
         results[jid].reserved = (uint32_t)(ph_acc_out >> 10);
+#elif defined(LZF_DBG_ROUNDS)
+        results[jid].reserved = LZF_DBG_ROUNDS == 1 ? dbg_rounds : dbg_batches;
 #else
         results[jid].reserved = (uint32_t)((clock64() - t_start) >> 10);   // diagnostic: shader kilo-cycles spent on this job
 #endif
