@@ -549,3 +549,33 @@ def test_compress_many_in_pipelined_groups_is_still_the_reference_frame(kw):
         assert s1["device_block_hashes"] - s0["device_block_hashes"] == sum((len(d) + 65535) // 65536 for d in datas)
     back = framed.decompress_frames(frames, dictionary=kw.get("dictionary", b""), caps=[len(d) + 64 for d in datas])
     assert back == [(0, d) for d in datas]
+
+
+def test_frames_written_by_liblz4_decode_on_the_gpu_and_ours_in_liblz4():
+    """Frame-level interop with the C implementation (fuzz/fuzz_targets/interop_decode.rs:6-31): the committed LZ4F_compressFrame
+    frames (tests/golden/lz4f_frames.*: HC levels, linked blocks, block checksums, content size, stored blocks) decode on the GPU —
+    whole-frame driver, block-by-block C reader and the streaming Python reader — and, when liblz4 is on the box, LZ4F_decompress
+    reads the GPU's frames.  An independent pin of the frame layer: liblz4 shares no code with this repository."""
+    import io
+    import liblz4_ffi as c
+    J = json.load(open(os.path.join(GOLD, "lz4f_frames.json")))
+    blob = open(os.path.join(GOLD, "lz4f_frames.bin"), "rb").read()
+    frames, datas = [], []
+    for fr in J["frames"]:
+        frames.append(blob[fr["offset"]: fr["offset"] + fr["length"]])
+        datas.append(eval(fr["input"], {"synth": synth}).tobytes())
+        assert [len(datas[-1]), "%08x" % o.xxh32(datas[-1])] == fr["in"]
+    got = framed.decompress_frames(frames, caps=[len(d) + 64 for d in datas], with_consumed=True)
+    assert got == [(0, d, len(f)) for d, f in zip(datas, frames)]
+    for f, d in zip(frames, datas):
+        r = framed.FrameBlockReader(f)
+        out = b""
+        while not r.finished():
+            out += r.decode_block()
+        assert out == d and r.consumed() == len(f)
+        assert framed.LZ4FrameReader(io.BytesIO(f), readahead=3).read() == d
+    if c.available():
+        data = synth.silesia_mix(10 << 20, (10 << 20) + 400_000).tobytes()
+        for kw in (dict(), dict(block_size=64 << 10), dict(block_size=64 << 10, independent_blocks=False), dict(block_size=256 << 10, block_checksums=True)):
+            g, _ = settings_pair(**kw)
+            assert c.lz4f_decompress(g.compress(data), len(data) + 64) == (True, data), kw

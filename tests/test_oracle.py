@@ -292,3 +292,28 @@ def test_hc_fixtures_decode_with_the_oracle():
         data = eval(b["input"], {"synth": synth}).tobytes()
         assert [len(data), "%08x" % o.xxh32(data)] == b["in"]
         assert o.decompress_raw(comp, limit=len(data)) == (0, data)
+
+
+def test_lz4f_fixture_frames_decode_with_the_oracle():
+    """tests/golden/lz4f_frames.*: frames written by liblz4's own frame layer (LZ4F_compressFrame, levels 0 / 4 / 9: the reference's
+    interop_decode fuzz target) decode to the regenerated inputs, every byte of the frame consumed."""
+    J = json.load(open(os.path.join(GOLD, "lz4f_frames.json")))
+    blob = open(os.path.join(GOLD, "lz4f_frames.bin"), "rb").read()
+    assert len(J["frames"]) == 8
+    for fr in J["frames"]:
+        frame = blob[fr["offset"]: fr["offset"] + fr["length"]]
+        assert [len(frame), "%08x" % o.xxh32(frame)] == fr["frame"]
+        data = eval(fr["input"], {"synth": synth}).tobytes()
+        assert [len(data), "%08x" % o.xxh32(data)] == fr["in"]
+        assert o.frame_decompress(frame, cap=len(data) + 64) == (0, data, len(frame))
+
+
+@pytest.mark.skipif(not c.available(), reason="liblz4 not installed")
+def test_liblz4_frame_layer_reads_oracle_frames():
+    """The other direction, live: LZ4F_decompress accepts the oracle's frames over the flag matrix (the frame FORMAT is pinned by an
+    implementation that shares no code with this repository)."""
+    data = synth.silesia_mix(10 << 20, (10 << 20) + 400_000).tobytes()
+    for kw in (dict(), dict(block_size=64 << 10), dict(block_size=64 << 10, independent_blocks=False), dict(block_size=256 << 10, block_checksums=True),
+               dict(block_size=64 << 10, content_checksum=False, block_checksums=True, independent_blocks=False), dict(content_size=len(data))):
+        f = o.frame_compress(data, o.make_settings(**kw))[1]
+        assert c.lz4f_decompress(f, len(data) + 64) == (True, data), kw
