@@ -63,48 +63,6 @@ __global__ void lzf_decompress_paired_kernel(const lzf_decompress_job* __restric
 LZF_PAIRED_VARIANTS(LZF_EXTP)
 #undef LZF_EXTP
 #ifdef LZF_ANALYSIS
-// Region-walk parser + the same copy stage (lz4_decompress_walk.hip): X(name, ring bytes, region bytes, token-list entries).
-template <int RING, int S, int TOKCAP>
-__global__ void lzf_decompress_walk_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
-                                           const uint32_t* __restrict__ perm);
-#define LZF_WALK_VARIANTS(X) \
-    X(walk48, 4096, 48, 640)  \
-    X(walk64, 4096, 64, 768)  \
-    X(walk96, 4096, 96, 1152) \
-    X(walk128, 4096, 128, 1536)
-#define LZF_EXTK(NAME, RG, S_, T) extern template __global__ void lzf_decompress_walk_kernel<RG, S_, T>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*);
-LZF_WALK_VARIANTS(LZF_EXTK)
-#undef LZF_EXTK
-// Pair kernel with the second copy stage (lz4_decompress_v4.hip): X(name, window bytes, region bytes, token-list entries, parser)
-// parser 0 = tabulating (nxt[] / ex[]), 1 = region walk.
-template <int W, int S, int TOKCAP, int PARSER>
-__global__ void lzf_decompress_v4_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
-                                         const uint32_t* __restrict__ perm);
-#define LZF_V4_VARIANTS(X) \
-    X(v4t24, 4096, 24, 384, 0)   \
-    X(v4t48, 4096, 48, 640, 0)   \
-    X(v4t24w6, 6144, 24, 384, 0) \
-    X(v4t24w8, 8192, 24, 384, 0) \
-    X(v4w64, 4096, 64, 768, 1)   \
-    X(v4w96, 4096, 96, 1152, 1)
-#define LZF_EXT4(NAME, W_, S_, T, P) extern template __global__ void lzf_decompress_v4_kernel<W_, S_, T, P>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*);
-LZF_V4_VARIANTS(LZF_EXT4)
-#undef LZF_EXT4
-// Fifth generation (lz4_decompress_v5.hip): X(name, window bytes, region bytes).  The token list of a chunk lives in global
-// scratch: 2 x LZF_V5_LISTWORDS(region) 32-bit words per workgroup of the launch.
-template <int W, int S, bool STAGED>
-__global__ void lzf_decompress_v5_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
-                                         const uint32_t* __restrict__ perm, uint32_t* __restrict__ scratch, uint32_t base);
-#define LZF_V5_TOKCAP(S_) ((64 * (S_)) / 3 + 1)
-#define LZF_V5_LISTWORDS(S_) ((uint32_t)((LZF_V5_TOKCAP(S_) + 64 + 63) / 64 * 64))
-#define LZF_V5_VARIANTS(X) \
-    X(v5s512, 4096, 512, false)  \
-    X(v5l256, 4096, 256, true)   \
-    X(v5l128, 4096, 128, true)   \
-    X(v5l384, 4096, 384, true)
-#define LZF_EXT5(NAME, W_, S_, ST) extern template __global__ void lzf_decompress_v5_kernel<W_, S_, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*, uint32_t*, uint32_t);
-LZF_V5_VARIANTS(LZF_EXT5)
-#undef LZF_EXT5
 // Sixth generation (lz4_decompress_v6.hip): parse and copy as two launches; X(name, window bytes, region bytes).
 __global__ void lzf_v6_plan_kernel(const lzf_decompress_job* __restrict__ jobs, uint32_t n_jobs, uint32_t base, uint32_t stride, uint32_t cnt, const uint32_t* __restrict__ perm,
                                    uint32_t chunk_bytes, uint64_t* __restrict__ tok_off, uint64_t* __restrict__ tab_off);

@@ -9,7 +9,7 @@
 //                         pair per chunk.
 //   lzf_v6_copy_kernel    one wavefront per block: lz4_decompress_copy3.inc over the listed tokens (linear LDS window, batches
 //                         of 64 sequences, token words / compressed bytes prefetched one batch ahead).
-// Splitting the pair of lz4_decompress_v5.hip in two launches doubles the copy waves a CU holds (they are the critical path)
+// Splitting the pair of (retired) v5 pair kernel in two launches doubles the copy waves a CU holds (they are the critical path)
 // and lets each kernel have its own register budget; the price is the token lists in HBM (4 bytes per sequence written and
 // read once: + ~30 % traffic on top of the compressed and decoded bytes).
 #include "lzf_device.h"

@@ -166,7 +166,7 @@ def _analysis_env(**kw):
 
 
 @pytest.mark.parametrize("variant", ["auto", "wave", "staged16", "staged32", "direct4w", "win512", "win1024", "paired16", "paired24", "paired48", "paired256",
-                                     "walk64", "v4t24", "v5s512", "v6l256", "ordered"])
+                                     "v6l256", "ordered"])
 def test_every_decompress_kernel_generation(variant):
     """Every kernel generation kept in the analysis library (and every ring/region geometry) implements the same contract.
     "ordered": the longest-first launch order that large batches get, forced on for these small ones."""
