@@ -19,7 +19,7 @@ ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.environ.get("LZF_LIB_PATH") or os.path.join(PKG_DIR, "liblzfear_hip.so")   # override: analysis builds only
 ANALYSIS_LIB_PATH = os.path.join(PKG_DIR, "liblzfear_hip_analysis.so")
 
-PRODUCT_HIP = ["capi.hip", "lz4_decompress_batched.hip", "lz4_decompress_paired.hip", "lz4_compress.hip",
+PRODUCT_HIP = ["capi.hip", "lz4_decompress_batched.hip", "lz4_decompress_paired.hip", "lz4_decompress_seg.hip", "lz4_compress.hip",
                "lz4_compress_compact.hip", "aux_kernels.hip"]
 ANALYSIS_HIP = ["lz4_decompress.hip", "lz4_decompress_windowed.hip", "lz4_decompress_v6.hip"]
 CXX_SOURCES = ["frame.cpp", "host_staging.cpp"]

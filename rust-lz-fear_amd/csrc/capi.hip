@@ -81,6 +81,85 @@ constexpr auto k_compact_dry = lzf::lzf_compress_compact_kernel<true>;
 constexpr auto k_general_u32 = lzf::lzf_compress_wave_kernel<LZF_TABLE_U32>;
 constexpr auto k_general_u16 = lzf::lzf_compress_wave_kernel<LZF_TABLE_U16>;
 
+// ---- the segmented pipeline (lz4_decompress_seg.hip): geometry, scratch, launches ------------------------------------
+constexpr uint32_t kSegMaxIn = 4u * 1024u * 1024u + 32u * 1024u;     // a 4 MiB block at LZ4's worst case, rounded up
+constexpr uint32_t kSegMinIn = 64u * 1024u;                          // smaller blocks are done sooner by one workgroup
+constexpr uint32_t kSegMaxJobs = 2048;                               // beyond this the chip is full with one workgroup per block
+constexpr uint64_t kSegRecsPerJob = 448u * 1024u;                    // arena: records per job on average (16 bytes each)
+
+struct SegScratch {
+    void* base = nullptr;
+    lzf::seg_ctx ctx{};
+    size_t bytes = 0;
+};
+inline uint32_t seg_nch_host(uint32_t len) { return len <= lzf::kSegChunk ? 1u : 1u + (len - lzf::kSegChunk + lzf::kSegStride - 1u) / lzf::kSegStride; }
+
+// lays the scratch areas of a call out in one stream-ordered allocation; false (and nothing allocated) when the pool has no room
+bool seg_alloc(SegScratch& s, const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n, uint32_t min_in, hipStream_t st) {
+    lzf::seg_ctx& c = s.ctx;
+    c.jobs = d_jobs; c.results = d_results; c.n_jobs = n;
+    c.max_in = kSegMaxIn; c.min_in = min_in;
+    c.maxch = seg_nch_host(kSegMaxIn);
+    c.maxtile = (kSegMaxIn + lzf::kSegTile - 1u) / lzf::kSegTile;
+    c.rec_cap = (uint64_t)n * kSegRecsPerJob;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_st = take(sizeof(lzf::seg_job) * (size_t)n);
+    const size_t o_top = take(sizeof(unsigned long long));
+    const size_t o_x = take(sizeof(uint32_t) * (size_t)n * c.maxch);
+    const size_t o_vf = take(sizeof(uint32_t) * (size_t)n * c.maxch);
+    const size_t o_tt = take(sizeof(uint32_t) * (size_t)n * c.maxtile);
+    const size_t o_to = take(sizeof(uint32_t) * (size_t)n * c.maxtile);
+    const size_t o_bits = take(sizeof(uint32_t) * (size_t)n * c.maxch * lzf::kSegChunkWords);
+    const size_t o_recs = take(sizeof(lzf::u32x4) * (size_t)c.rec_cap);
+    if (hipMallocAsync(&s.base, off, st) != hipSuccess) { (void)hipGetLastError(); s.base = nullptr; return false; }
+    s.bytes = off;
+    uint8_t* b = static_cast<uint8_t*>(s.base);
+    c.st = reinterpret_cast<lzf::seg_job*>(b + o_st);
+    c.rec_top = reinterpret_cast<unsigned long long*>(b + o_top);
+    c.xexit = reinterpret_cast<uint32_t*>(b + o_x);
+    c.vfrom = reinterpret_cast<uint32_t*>(b + o_vf);
+    c.tile_tok = reinterpret_cast<uint32_t*>(b + o_tt);
+    c.tile_out = reinterpret_cast<uint32_t*>(b + o_to);
+    c.bits = reinterpret_cast<uint32_t*>(b + o_bits);
+    c.recs = reinterpret_cast<lzf::u32x4*>(b + o_recs);
+    return true;
+}
+inline uint32_t seg_grid(uint32_t target, uint32_t n, uint32_t cap) {
+    uint32_t g = target / n; if (g < 1u) g = 1u; if (g > cap) g = cap; return g;
+}
+// stages: 1 plan, 2 parse, 3 seam, 4 tilesum, 5 scan, 6 records, 7 levels, 8 resolve (all when upto >= 8)
+int seg_launch(const lzf::seg_ctx& c, uint32_t upto, hipStream_t st) {
+    const uint32_t n = c.n_jobs;
+    LAUNCH(lzf::lzf_seg_plan_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, c);
+    if (upto >= 2) LAUNCH(lzf::lzf_seg_parse_kernel, dim3(seg_grid(8192u, n, c.maxch), n), dim3(64), 0, st, c);
+    if (upto >= 3) LAUNCH(lzf::lzf_seg_seam_kernel, dim3(n), dim3(64), 0, st, c);
+    if (upto >= 4) LAUNCH(lzf::lzf_seg_tilesum_kernel, dim3(seg_grid(32768u, n, c.maxtile), n), dim3(64), 0, st, c);
+    if (upto >= 5) LAUNCH(lzf::lzf_seg_scan_kernel, dim3(n), dim3(64), 0, st, c);
+    if (upto >= 6) LAUNCH(lzf::lzf_seg_records_kernel, dim3(seg_grid(32768u, n, c.maxtile), n), dim3(64), 0, st, c);
+    if (upto >= 7) LAUNCH(lzf::lzf_seg_levels_kernel, dim3(seg_grid(32768u, n, 16384u), n), dim3(64), 0, st, c);
+    if (upto >= 8) {
+        if (n <= 2u * cu_count()) LAUNCH(lzf::lzf_seg_resolve_kernel<65536>, dim3(n), dim3(64), 0, st, c);
+        else LAUNCH(lzf::lzf_seg_resolve_kernel<32768>, dim3(n), dim3(64), 0, st, c);
+    }
+    return LZF_OK;
+}
+// The whole call: pipeline, then the pair kernel over what the pipeline did not finish.
+int seg_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n, uint32_t min_in, hipStream_t st, bool* used) {
+    SegScratch s;
+    *used = false;
+    if (!seg_alloc(s, d_jobs, d_results, n, min_in, st)) return LZF_OK;      // (no scratch: the caller launches the pair kernel over everything)
+    *used = true;
+    int rc = seg_launch(s.ctx, 8u, st);
+    if (rc == LZF_OK) {
+        hipLaunchKernelGGL(k_paired48, dim3(n), dim3(128), 0, st, d_jobs, d_results, n, (const uint32_t*)nullptr, (const lzf::seg_job*)s.ctx.st);
+        if (hipGetLastError() != hipSuccess) rc = LZF_E_HIP;
+    }
+    if (hipFreeAsync(s.base, st) != hipSuccess && rc == LZF_OK) rc = LZF_E_HIP;
+    if (rc != LZF_OK) g_last_error = "segmented decompress: launch failed";
+    return rc;
+}
+
 #ifdef LZF_ANALYSIS
 #include "capi_analysis.inc"
 #endif
@@ -176,15 +255,29 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
         return rc;
     }
 #endif
+    // Batches that leave the chip mostly empty with one workgroup per block: the segmented pipeline (a block decoded by many
+    // wavefronts), then the pair kernel over the jobs it left (prefix / existing output, errors, sizes outside its window).
+    uint32_t seg_min_in = kSegMinIn; bool seg_on = n_jobs <= kSegMaxJobs;
+#ifdef LZF_ANALYSIS
+    { static const int mode = [] { const char* e = getenv("LZF_DECOMPRESS_KERNEL"); return !e ? 0 : !strcmp(e, "seg") ? 1 : !strcmp(e, "noseg") ? 2 : 0; }();
+      static const uint32_t min_in = [] { const char* e = getenv("LZF_SEG_MIN_IN"); return e ? (uint32_t)atol(e) : 0u; }();
+      if (mode == 1) { seg_on = true; seg_min_in = min_in; }
+      if (mode == 2) seg_on = false; }
+#endif
+    if (seg_on) {
+        bool used = false;
+        rc = seg_decompress(d_jobs, d_results, n_jobs, seg_min_in, st, &used);
+        if (rc != LZF_OK || used) { if (perm) HIP_TRY(hipFreeAsync(perm, st)); return rc; }
+    }
     // The producer/consumer pair kernel, with 48-byte regions while every block's workgroup is resident at once (lowest
     // latency per block: the copy stage is the critical path, the parse rides along) and 24-byte regions beyond that
     // (smaller LDS footprint, more blocks in flight); batches of more than eight times that many blocks (small blocks,
     // typically) go to the one-wave staged16 kernel, which has no per-block pipeline to fill.
     const uint32_t resident48 = 8u * cu_count();          // workgroups of the 48-byte form one device holds: 8 per CU (20 KB of LDS each)
     if (n_jobs <= resident48)
-        LAUNCH(k_paired48, dim3(n_jobs), dim3(128), 0, st, d_jobs, d_results, n_jobs, cperm);
+        LAUNCH(k_paired48, dim3(n_jobs), dim3(128), 0, st, d_jobs, d_results, n_jobs, cperm, (const lzf::seg_job*)nullptr);
     else if (n_jobs <= 8u * resident48)
-        LAUNCH(k_paired24, dim3(n_jobs), dim3(128), 0, st, d_jobs, d_results, n_jobs, cperm);
+        LAUNCH(k_paired24, dim3(n_jobs), dim3(128), 0, st, d_jobs, d_results, n_jobs, cperm, (const lzf::seg_job*)nullptr);
     else
         LAUNCH(k_staged16, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, cperm);
     if (perm) HIP_TRY(hipFreeAsync(perm, st));
@@ -266,6 +359,32 @@ int lzf_xxh32_batch(const uint8_t* const* d_ptrs, const uint64_t* d_lens, uint32
     HIP_TRY(hipGetLastError());
     return LZF_OK;
 }
+
+#ifdef LZF_ANALYSIS
+// Analysis only: run the segmented pipeline up to a stage and copy its scratch areas to host buffers (NULL = skip).
+// geom[0..3] = maxch, maxtile, chunk words, records in the arena.
+int lzf_debug_seg(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n, uint32_t min_in, uint32_t upto,
+                  void* h_state, void* h_bits, void* h_xexit, void* h_vfrom, void* h_tile_tok, void* h_tile_out, void* h_recs, uint64_t recs_bytes,
+                  uint32_t* geom) {
+    int rc = ensure_device();
+    if (rc < 0) return rc;
+    SegScratch s;
+    if (!seg_alloc(s, d_jobs, d_results, n, min_in, nullptr)) return LZF_E_HIP;
+    const lzf::seg_ctx& c = s.ctx;
+    rc = seg_launch(c, upto, nullptr);
+    HIP_TRY(hipDeviceSynchronize());
+    if (geom) { geom[0] = c.maxch; geom[1] = c.maxtile; geom[2] = lzf::kSegChunkWords; geom[3] = (uint32_t)c.rec_cap; }
+    if (h_state) HIP_TRY(hipMemcpy(h_state, c.st, sizeof(lzf::seg_job) * n, hipMemcpyDeviceToHost));
+    if (h_bits) HIP_TRY(hipMemcpy(h_bits, c.bits, sizeof(uint32_t) * (size_t)n * c.maxch * lzf::kSegChunkWords, hipMemcpyDeviceToHost));
+    if (h_xexit) HIP_TRY(hipMemcpy(h_xexit, c.xexit, sizeof(uint32_t) * (size_t)n * c.maxch, hipMemcpyDeviceToHost));
+    if (h_vfrom) HIP_TRY(hipMemcpy(h_vfrom, c.vfrom, sizeof(uint32_t) * (size_t)n * c.maxch, hipMemcpyDeviceToHost));
+    if (h_tile_tok) HIP_TRY(hipMemcpy(h_tile_tok, c.tile_tok, sizeof(uint32_t) * (size_t)n * c.maxtile, hipMemcpyDeviceToHost));
+    if (h_tile_out) HIP_TRY(hipMemcpy(h_tile_out, c.tile_out, sizeof(uint32_t) * (size_t)n * c.maxtile, hipMemcpyDeviceToHost));
+    if (h_recs) { uint64_t nb = sizeof(lzf::u32x4) * c.rec_cap; if (nb > recs_bytes) nb = recs_bytes; HIP_TRY(hipMemcpy(h_recs, c.recs, nb, hipMemcpyDeviceToHost)); }
+    HIP_TRY(hipFree(s.base));
+    return rc;
+}
+#endif
 
 // ---------------------------------------------------------------------------------------
 // host-buffer helpers: stage -> launch -> copy back.  Synchronous.  Every job's bytes travel through the pinned slab of

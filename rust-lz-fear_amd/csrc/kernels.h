@@ -44,9 +44,11 @@ LZF_WINDOWED_VARIANTS(LZF_EXTW)
 #undef LZF_EXTW
 #endif
 // Producer / consumer pairs (lz4_decompress_paired.hip): X(name, ring bytes, region bytes, token-list entries).
+struct seg_job;
+// done (optional): state array of the segmented pipeline; a job it finished (done[jid].done != 0) is skipped
 template <int RING, int S, int TOKCAP>
 __global__ void lzf_decompress_paired_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
-                                             const uint32_t* __restrict__ perm);
+                                             const uint32_t* __restrict__ perm, const seg_job* __restrict__ done);
 #ifdef LZF_ANALYSIS
 #define LZF_PAIRED_VARIANTS(X) \
     X(paired16, 4096, 16, 256) \
@@ -59,7 +61,7 @@ __global__ void lzf_decompress_paired_kernel(const lzf_decompress_job* __restric
     X(paired24, 4096, 24, 384) \
     X(paired48, 4096, 48, 640)
 #endif
-#define LZF_EXTP(NAME, RG, S_, T) extern template __global__ void lzf_decompress_paired_kernel<RG, S_, T>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*);
+#define LZF_EXTP(NAME, RG, S_, T) extern template __global__ void lzf_decompress_paired_kernel<RG, S_, T>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*, const seg_job*);
 LZF_PAIRED_VARIANTS(LZF_EXTP)
 #undef LZF_EXTP
 #ifdef LZF_ANALYSIS
@@ -85,6 +87,59 @@ __global__ void lzf_v6_copy_kernel(const lzf_decompress_job* __restrict__ jobs, 
 LZF_V6_VARIANTS(LZF_EXT6)
 #undef LZF_EXT6
 #endif  // LZF_ANALYSIS
+// ---------------------------------------------------------------------------------------------------------------------
+// Segmented decompress (lz4_decompress_seg.hip): one block decoded by MANY wavefronts, as a pipeline of launches over the
+// whole batch.  Used for batches that leave the chip mostly empty with one workgroup per block (per-block latency regime).
+//   plan      per job: eligible?  (no prefix, no existing output, size window)  chunk / tile counts
+//   parse     one wave per 16 KiB chunk of compressed bytes (chunks overlap by 2 KiB): speculative region-walk parse from
+//             the chunk's first byte -> bit map "a token of this chunk's chain starts here" + the chain's exit
+//   seam      one wave per job: chunk h's chain is the true one from the position where the true chain (exit of chunk
+//             h - 1) steps on one of its marked tokens; almost always that is the exit itself (the chains met inside the
+//             overlap), otherwise a short walk patches the bit map
+//   tilesum   one wave per 2 KiB tile of compressed bytes: tokens and output bytes of the tile
+//   scan      one wave per job: exclusive sums over the tiles, record space from the arena
+//   records   one wave per tile: decode every token, absolute output positions, error checks, LITERALS -> out,
+//             one 16-byte record per sequence {lo, mo, M, off}
+//   levels    one wave per 64 records: dependency level of every match inside its batch (level k copies only from
+//             bytes that are final once levels < k are done)
+//   resolve   one wave per job, the only serial stage: ring of the recent output in LDS (filled with the literals
+//             already in place), per batch one LDS round per dependency level, flush with aligned 16-byte stores
+// A job that is not eligible, or in which any stage meets something it does not handle (every DecodeError, capacity,
+// arena exhausted), is left to the pair kernel, which runs last and skips the jobs the pipeline finished.
+// ---------------------------------------------------------------------------------------------------------------------
+struct seg_job {
+    uint32_t eligible, failed, done, nch;
+    uint32_t ntile, ntok, outb, pad;
+    uint64_t rec_off;            // first record of the job in the arena
+    uint64_t pad2;
+};
+struct seg_ctx {
+    const lzf_decompress_job* jobs;
+    lzf_job_result* results;
+    seg_job* st;
+    uint32_t* bits;              // [n_jobs][maxch][512]   token bit maps of the chunks' chains
+    uint32_t* xexit;             // [n_jobs][maxch]        first token at or beyond the chunk's end, on the chunk's chain
+    uint32_t* vfrom;             // [n_jobs][maxch]        position from which the chunk's bits are the true tokens (~0: none)
+    uint32_t* tile_tok;          // [n_jobs][maxtile]      tokens per tile, then (scan) first token of the tile
+    uint32_t* tile_out;          // [n_jobs][maxtile]      output bytes per tile, then (scan) first output byte of the tile
+    u32x4* recs;                 // arena of records
+    unsigned long long* rec_top; // bump pointer into the arena
+    uint64_t rec_cap;
+    uint32_t n_jobs, maxch, maxtile, max_in, min_in;
+};
+constexpr uint32_t kSegRegion = 256, kSegChunk = 64u * kSegRegion, kSegOverlap = 2048, kSegStride = kSegChunk - kSegOverlap;
+constexpr uint32_t kSegChunkWords = kSegChunk / 32u, kSegTile = 2048;
+__global__ void lzf_seg_plan_kernel(seg_ctx c);
+__global__ void lzf_seg_parse_kernel(seg_ctx c);
+__global__ void lzf_seg_seam_kernel(seg_ctx c);
+__global__ void lzf_seg_tilesum_kernel(seg_ctx c);
+__global__ void lzf_seg_scan_kernel(seg_ctx c);
+__global__ void lzf_seg_records_kernel(seg_ctx c);
+__global__ void lzf_seg_levels_kernel(seg_ctx c);
+template <int R>
+__global__ void lzf_seg_resolve_kernel(seg_ctx c);
+extern template __global__ void lzf_seg_resolve_kernel<32768>(seg_ctx);
+extern template __global__ void lzf_seg_resolve_kernel<65536>(seg_ctx);
 template <int KIND>
 __global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
                                          lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t skip_compact,

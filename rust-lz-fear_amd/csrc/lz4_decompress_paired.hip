@@ -15,7 +15,7 @@ namespace lzf {
 template <int RING, int S, int TOKCAP>
 __global__ __launch_bounds__(128) void lzf_decompress_paired_kernel(
     const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
-    const uint32_t* __restrict__ perm) {
+    const uint32_t* __restrict__ perm, const seg_job* __restrict__ done) {
     constexpr bool STAGE = true;
     constexpr uint32_t kMask = RING - 1;
     constexpr uint32_t kSpanMax = RING / 3;            // output bytes one batch may produce
@@ -37,6 +37,7 @@ __global__ __launch_bounds__(128) void lzf_decompress_paired_kernel(
 
     if (blockIdx.x >= n_jobs) return;
     const uint32_t jid = perm ? perm[blockIdx.x] : blockIdx.x;
+    if (done && done[jid].done) return;               // finished by the segmented pipeline (uniform over the workgroup)
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0: parser, 1: copier (uniform per wavefront)
     const lzf_decompress_job job = jobs[jid];
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(128) void lzf_decompress_paired_kernel(
     }
 }
 
-#define LZF_INSTP(NAME, RG, S_, T) template __global__ void lzf_decompress_paired_kernel<RG, S_, T>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*);
+#define LZF_INSTP(NAME, RG, S_, T) template __global__ void lzf_decompress_paired_kernel<RG, S_, T>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*, const seg_job*);
 LZF_PAIRED_VARIANTS(LZF_INSTP)
 #undef LZF_INSTP
 
