@@ -139,8 +139,21 @@ int seg_launch(const lzf::seg_ctx& c, uint32_t upto, hipStream_t st) {
     if (upto >= 6) LAUNCH(lzf::lzf_seg_records_kernel, dim3(seg_grid(32768u, n, c.maxtile), n), dim3(64), 0, st, c);
     if (upto >= 7) LAUNCH(lzf::lzf_seg_levels_kernel, dim3(seg_grid(32768u, n, 16384u), n), dim3(64), 0, st, c);
     if (upto >= 8) {
-        if (n <= 2u * cu_count()) LAUNCH(lzf::lzf_seg_resolve_kernel<65536>, dim3(n), dim3(64), 0, st, c);
-        else LAUNCH(lzf::lzf_seg_resolve_kernel<32768>, dim3(n), dim3(64), 0, st, c);
+        // the ring of a block: 128 KiB holds every distance LZ4 can express (no read-backs from HBM) while a CU has one block,
+        // 64 / 32 KiB with read-backs for the oldest few per cent of the sources beyond that
+        bool single = false;
+#ifdef LZF_ANALYSIS
+        { static const bool e = [] { const char* v = getenv("LZF_SEG_RESOLVE"); return v && !strcmp(v, "single"); }(); single = e; }
+#endif
+        if (single) {
+            if (n <= cu_count()) LAUNCH(lzf::lzf_seg_resolve_kernel<131072>, dim3(n), dim3(64), 0, st, c);
+            else if (n <= 2u * cu_count()) LAUNCH(lzf::lzf_seg_resolve_kernel<65536>, dim3(n), dim3(64), 0, st, c);
+            else LAUNCH(lzf::lzf_seg_resolve_kernel<32768>, dim3(n), dim3(64), 0, st, c);
+        } else {
+            if (n <= cu_count()) LAUNCH(lzf::lzf_seg_resolve_pair_kernel<131072>, dim3(n), dim3(128), 0, st, c);
+            else if (n <= 2u * cu_count()) LAUNCH(lzf::lzf_seg_resolve_pair_kernel<65536>, dim3(n), dim3(128), 0, st, c);
+            else LAUNCH(lzf::lzf_seg_resolve_pair_kernel<32768>, dim3(n), dim3(128), 0, st, c);
+        }
     }
     return LZF_OK;
 }

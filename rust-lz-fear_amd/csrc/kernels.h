@@ -138,8 +138,14 @@ __global__ void lzf_seg_records_kernel(seg_ctx c);
 __global__ void lzf_seg_levels_kernel(seg_ctx c);
 template <int R>
 __global__ void lzf_seg_resolve_kernel(seg_ctx c);
+template <int R>
+__global__ void lzf_seg_resolve_pair_kernel(seg_ctx c);
+extern template __global__ void lzf_seg_resolve_pair_kernel<32768>(seg_ctx);
+extern template __global__ void lzf_seg_resolve_pair_kernel<65536>(seg_ctx);
+extern template __global__ void lzf_seg_resolve_pair_kernel<131072>(seg_ctx);
 extern template __global__ void lzf_seg_resolve_kernel<32768>(seg_ctx);
 extern template __global__ void lzf_seg_resolve_kernel<65536>(seg_ctx);
+extern template __global__ void lzf_seg_resolve_kernel<131072>(seg_ctx);
 template <int KIND>
 __global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
                                          lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t skip_compact,

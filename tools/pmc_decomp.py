@@ -35,3 +35,11 @@ for it in range(reps):
 if os.environ.get("LZF_PRINT_RESERVED"):
     r2 = device.results_to_host(d_res2, m)
     print(f"reserved: mean {r2['reserved'].mean():.1f} kcycles/job, sum {int(r2['reserved'].sum())} ; status ok {int((r2['status'] == 0).sum())}/{m}", flush=True)
+if os.environ.get("LZF_VERIFY"):
+    r2 = device.results_to_host(d_res2, m)
+    bad = 0
+    for k in range(m):
+        b = int(idx[k]); ln = min(BS, len(data) - b * BS)
+        if r2['status'][k] != 0 or int(r2['out_len'][k]) != ln or not torch.equal(d_dec[k * BS:k * BS + ln], d_in[b * BS:b * BS + ln]):
+            bad += 1
+    print(f"verify: {m - bad}/{m} jobs bit-exact", flush=True)

@@ -197,7 +197,11 @@ def run(blocks, min_in, upto, verbose=True):
             ok_all = False
             print(f"  [{name}] len {len(d)} comp {len(cdat)} toks {len(toks)} FAILED: " + "; ".join(msgs))
         elif verbose:
-            print(f"  [{name}] ok (comp {len(cdat)}, {len(toks)} tokens, failed={s['failed']}, kcycles {res[i]['reserved']})")
+            extra = ""
+            if int(s["pad"]):
+                p2 = int(s["pad2"])
+                extra = f", rounds {int(s['pad'])} ({int(s['pad']) / max(1, (len(toks) + 63) // 64):.2f}/batch), kcycles rounds {p2 & 0xFFFFFFFF} pre {((p2 >> 32) & 0xFFFF) << 4} flush+loop {((p2 >> 48) & 0xFFFF) << 4}"
+            print(f"  [{name}] ok (comp {len(cdat)}, {len(toks)} tokens, failed={s['failed']}, kcycles {res[i]['reserved']}{extra})")
     return ok_all
 
 
