@@ -84,7 +84,7 @@ constexpr auto k_general_u16 = lzf::lzf_compress_wave_kernel<LZF_TABLE_U16>;
 // ---- the segmented pipeline (lz4_decompress_seg.hip): geometry, scratch, launches ------------------------------------
 constexpr uint32_t kSegMaxIn = 4u * 1024u * 1024u + 32u * 1024u;     // a 4 MiB block at LZ4's worst case, rounded up
 constexpr uint32_t kSegMinIn = 64u * 1024u;                          // smaller blocks are done sooner by one workgroup
-constexpr uint32_t kSegMaxJobs = 2048;                               // beyond this the chip is full with one workgroup per block
+constexpr uint32_t kSegMaxJobs = 768;                                // (three blocks per CU) beyond this one workgroup per block fills the chip and wins
 constexpr uint64_t kSegRecsPerJob = 448u * 1024u;                    // arena: records per job on average (16 bytes each)
 
 struct SegScratch {
@@ -102,6 +102,9 @@ bool seg_alloc(SegScratch& s, const lzf_decompress_job* d_jobs, lzf_job_result* 
     c.maxch = seg_nch_host(kSegMaxIn);
     c.maxtile = (kSegMaxIn + lzf::kSegTile - 1u) / lzf::kSegTile;
     c.rec_cap = (uint64_t)n * kSegRecsPerJob;
+    // the ring of a block: 128 KiB holds every distance LZ4 can express (no read-backs from HBM) while a CU has one block,
+    // 64 / 32 KiB with read-backs for the oldest few per cent of the sources beyond that
+    c.ring_bytes = n <= cu_count() ? 131072u : n <= 2u * cu_count() ? 65536u : 32768u;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_st = take(sizeof(lzf::seg_job) * (size_t)n);
@@ -139,21 +142,9 @@ int seg_launch(const lzf::seg_ctx& c, uint32_t upto, hipStream_t st) {
     if (upto >= 6) LAUNCH(lzf::lzf_seg_records_kernel, dim3(seg_grid(32768u, n, c.maxtile), n), dim3(64), 0, st, c);
     if (upto >= 7) LAUNCH(lzf::lzf_seg_levels_kernel, dim3(seg_grid(32768u, n, 16384u), n), dim3(64), 0, st, c);
     if (upto >= 8) {
-        // the ring of a block: 128 KiB holds every distance LZ4 can express (no read-backs from HBM) while a CU has one block,
-        // 64 / 32 KiB with read-backs for the oldest few per cent of the sources beyond that
-        bool single = false;
-#ifdef LZF_ANALYSIS
-        { static const bool e = [] { const char* v = getenv("LZF_SEG_RESOLVE"); return v && !strcmp(v, "single"); }(); single = e; }
-#endif
-        if (single) {
-            if (n <= cu_count()) LAUNCH(lzf::lzf_seg_resolve_kernel<131072>, dim3(n), dim3(64), 0, st, c);
-            else if (n <= 2u * cu_count()) LAUNCH(lzf::lzf_seg_resolve_kernel<65536>, dim3(n), dim3(64), 0, st, c);
-            else LAUNCH(lzf::lzf_seg_resolve_kernel<32768>, dim3(n), dim3(64), 0, st, c);
-        } else {
-            if (n <= cu_count()) LAUNCH(lzf::lzf_seg_resolve_pair_kernel<131072>, dim3(n), dim3(128), 0, st, c);
-            else if (n <= 2u * cu_count()) LAUNCH(lzf::lzf_seg_resolve_pair_kernel<65536>, dim3(n), dim3(128), 0, st, c);
-            else LAUNCH(lzf::lzf_seg_resolve_pair_kernel<32768>, dim3(n), dim3(128), 0, st, c);
-        }
+        if (c.ring_bytes == 131072u) LAUNCH(lzf::lzf_seg_resolve_pair_kernel<131072>, dim3(n), dim3(128), 0, st, c);
+        else if (c.ring_bytes == 65536u) LAUNCH(lzf::lzf_seg_resolve_pair_kernel<65536>, dim3(n), dim3(128), 0, st, c);
+        else LAUNCH(lzf::lzf_seg_resolve_pair_kernel<32768>, dim3(n), dim3(128), 0, st, c);
     }
     return LZF_OK;
 }

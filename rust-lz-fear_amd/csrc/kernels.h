@@ -126,6 +126,7 @@ struct seg_ctx {
     unsigned long long* rec_top; // bump pointer into the arena
     uint64_t rec_cap;
     uint32_t n_jobs, maxch, maxtile, max_in, min_in;
+    uint32_t ring_bytes;         // LDS ring of the resolve stage (32 / 64 / 128 KiB): the levels stage classes the records for it
 };
 constexpr uint32_t kSegRegion = 256, kSegChunk = 64u * kSegRegion, kSegOverlap = 2048, kSegStride = kSegChunk - kSegOverlap;
 constexpr uint32_t kSegChunkWords = kSegChunk / 32u, kSegTile = 2048;
@@ -137,15 +138,10 @@ __global__ void lzf_seg_scan_kernel(seg_ctx c);
 __global__ void lzf_seg_records_kernel(seg_ctx c);
 __global__ void lzf_seg_levels_kernel(seg_ctx c);
 template <int R>
-__global__ void lzf_seg_resolve_kernel(seg_ctx c);
-template <int R>
 __global__ void lzf_seg_resolve_pair_kernel(seg_ctx c);
 extern template __global__ void lzf_seg_resolve_pair_kernel<32768>(seg_ctx);
 extern template __global__ void lzf_seg_resolve_pair_kernel<65536>(seg_ctx);
 extern template __global__ void lzf_seg_resolve_pair_kernel<131072>(seg_ctx);
-extern template __global__ void lzf_seg_resolve_kernel<32768>(seg_ctx);
-extern template __global__ void lzf_seg_resolve_kernel<65536>(seg_ctx);
-extern template __global__ void lzf_seg_resolve_kernel<131072>(seg_ctx);
 template <int KIND>
 __global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
                                          lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t skip_compact,

@@ -629,12 +629,19 @@ __global__ __launch_bounds__(64) void lzf_seg_records_kernel(seg_ctx c) {
 }
 
 // =====================================================================================================================
-// levels: within a batch of 64 records, which matches copy from which
+// levels: within a batch of 64 records, which matches copy from which — and everything else the resolve stage needs to
+// know about a record, so that its two wavefronts compute nothing of it themselves
 // =====================================================================================================================
 // level(j) = 1 + max level of the matches (of the same batch) whose destination overlaps j's source bytes; 1 when there
 // are none (everything in front of the batch is final when the batch starts).  Destinations are disjoint and in stream
 // order, so the matches j depends on are a range of lanes [i_lo, i_hi], found by two binary searches; ranges wider than
 // two lanes use the running maximum up to i_hi (never too small: a larger level is only later, not wrong).
+// Output record (replaces {lo, mo, M, off}):  w0 = M,  w1 = biased destination (mo + rb, rb = out & 15),
+//   w2 = sub-batch (0..63) | level << 16 | class << 24,  w3 = off.
+// Sub-batches: consecutive sequences of the batch whose output spans at most ring / 8 bytes (greedy).
+// Classes: 0 no match | 1: 4..7 bytes | 2: 8..16 | 3: 17..32 | 4: 33..64 (all not overlapping, source inside the ring) |
+//   5 overlapping, <= 64 | 6 whole wave (longer, or wrapping around the ring) | 7 source (partly) older than what the ring
+//   is guaranteed to hold when the sub-batch is resolved: moved by the stager | 8 a sequence larger than a sub-batch.
 __global__ __launch_bounds__(64) void lzf_seg_levels_kernel(seg_ctx c) {
     __shared__ uint32_t s_end[64], s_mo[64], s_lvl[64], s_pm[64];
     const uint32_t j = blockIdx.y;
@@ -643,16 +650,19 @@ __global__ __launch_bounds__(64) void lzf_seg_levels_kernel(seg_ctx c) {
     const uint32_t lane = threadIdx.x & 63u;
     LZF_GLOBAL u32x4* const recs = (LZF_GLOBAL u32x4*)c.recs + sj.rec_off;
     const uint32_t nb_all = (sj.ntok + 63u) / 64u;
+    const uint32_t R = c.ring_bytes, kSpan = R / 8u, kAheadB = 3u * kSpan + 64u;
+    const uint32_t rb = (uint32_t)(reinterpret_cast<uintptr_t>(c.jobs[j].out) & 15u);
     for (uint32_t b = blockIdx.x; b < nb_all; b += gridDim.x) {
         const uint32_t idx = b * 64u + lane;
-        const bool act = idx < sj.ntok;
+        const uint32_t nb = sj.ntok - b * 64u < 64u ? sj.ntok - b * 64u : 64u;
+        const bool act = lane < nb;
         u32x4 r = u32x4{0, 0, 0, 0};
         if (act) r = recs[idx];
-        const uint32_t mo = r[1], M = r[2], off = r[3] & 0xFFFFu;
+        const uint32_t lo = r[0], mo = r[1], M = r[2], off = r[3] & 0xFFFFu;
         const bool has = act && M != 0u;
         const uint32_t span = M < off ? M : off;
         const uint32_t s0 = mo - off, e0 = s0 + span;
-        const uint32_t ob = __builtin_amdgcn_readlane(r[0], 0);
+        const uint32_t ob = __builtin_amdgcn_readlane(lo, 0);
         __syncthreads();
         s_end[lane] = act ? mo + M : 0xFFFFFFFFu;
         s_mo[lane] = act ? mo : 0xFFFFFFFFu;
@@ -668,7 +678,6 @@ __global__ __launch_bounds__(64) void lzf_seg_levels_kernel(seg_ctx c) {
                 if (s_end[(a + step - 1u) & 63u] <= s0) a += step;
                 if (s_mo[(bb + step - 1u) & 63u] < e0) bb += step;
             }
-            // (a, bb in 0..63 by construction of the search; lane 63's end > s0 whenever dep)
             ilo = a; ihi = bb - 1u;
             any_dep = dep && bb >= 1u && ilo <= ihi && ihi < lane;
         }
@@ -688,66 +697,95 @@ __global__ __launch_bounds__(64) void lzf_seg_levels_kernel(seg_ctx c) {
                 if (!__any(ch)) break;
             }
         }
+        // ---- sub-batches and classes
+        const uint32_t endp = mo + M;
+        uint32_t sub = 0, cls = 0;
+        uint32_t a = 0, sidx = 0;
+        while (a < nb) {
+            const uint32_t sob = __builtin_amdgcn_readlane(lo, a);
+            const uint32_t bb0 = first_lane(__ballot(lane >= a && lane < nb && endp - sob > kSpan));
+            uint32_t e = bb0 < nb ? bb0 : nb;
+            const bool giant = e == a;
+            if (giant) e = a + 1u;
+            const uint32_t oe = __builtin_amdgcn_readlane(endp, e - 1u);
+            if (lane >= a && lane < e) {
+                sub = sidx;
+                if (giant) cls = 8u;
+                else if (M != 0u) {
+                    // what the ring holds for certain when this sub-batch is resolved: from fill pointer + fetch-ahead - ring on
+                    const uint32_t fpw = ((oe + rb + 15u) & ~15u) + kAheadB;
+                    const uint32_t lov = fpw > R ? fpw - R : 0u;
+                    const uint32_t sy = s0 + rb, dy = mo + rb;
+                    const uint32_t di = dy & (R - 1u), si = sy & (R - 1u);
+                    const bool wrap = di + M > R || si + M > R;
+                    if (sy < lov) cls = 7u;
+                    else if (M > 64u || wrap) cls = 6u;
+                    else if (off < M) cls = 5u;
+                    else cls = M < 8u ? 1u : M <= 16u ? 2u : M <= 32u ? 3u : 4u;
+                }
+            }
+            a = e; ++sidx;
+        }
         if (act) {
-            const uint32_t flags = (has && M > 64u) ? kFlagCoop : 0u;
-            recs[idx][3] = off | (lvl << 16) | (flags << 24);
+            u32x4 w; w[0] = M; w[1] = mo + rb; w[2] = sub | (lvl << 16) | (cls << 24); w[3] = off;
+            recs[idx] = w;
         }
     }
 }
 
 // =====================================================================================================================
-// resolve: the dependent match copies of a block, one LDS round per level
+// resolve: the dependent match copies of a block — a pair of wavefronts per block
 // =====================================================================================================================
 // Biased positions y = x + rb (rb = out & 15): y % 16 == 0 <=> out + x is 16-byte aligned; ring index = y & (R - 1).
-// The ring holds y in [max(fp - R, vlo), fp): fp = filled up to (whole granules, from `out`, where the literals already
-// are); fl = flushed up to (everything below is final in HBM).
-// Software pipeline, one batch of 64 records per iteration: the records of batch b + 2 and the granules of batch b + 1
-// are loaded while batch b is resolved, so that no global round trip sits between two batches.
+// The STAGER (wave 1) does everything that is not the dependency chain: the ring's granules in from `out` (the literals are
+// there), finished granules out to HBM, the few sources that are older than the ring (class 7: from HBM), sequences larger
+// than a sub-batch (class 8: HBM -> HBM, then the ring's history is read back).  The RESOLVER (wave 0) runs the rounds of
+// sub-batch after sub-batch: one LDS round trip per dependency level.  Both read the records (levels stage) on their own.
+// Tickets = sub-batches in stream order: the stager publishes ticket t with ctl[0] = t + 1 after its LDS writes, the
+// resolver answers ctl[1] = t + 1 after its own; LDS executes one wave's accesses in order, so a flag is never seen before
+// the data.  The stager runs at most NS tickets ahead; the levels stage classed the sources with that fetch-ahead in mind.
 template <int R>
-__global__ __launch_bounds__(64) void lzf_seg_resolve_kernel(seg_ctx c) {
+__global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
     constexpr uint32_t kMask = (uint32_t)R - 1u;
-    constexpr uint32_t kSpan = 4096;                   // output bytes one sub-batch may produce
-    static_assert(R >= 32768, "far sources must be flushed: ring >= deferred flush (8 KiB) + two sub-batches + fetch-ahead (4 KiB)");
+    constexpr uint32_t kSpan = (uint32_t)R / 8u;       // output bytes one sub-batch may produce
+    constexpr uint32_t NS = 3;                         // tickets the stager may be ahead
     __shared__ __attribute__((aligned(16))) uint8_t ring[R];
+    __shared__ uint32_t ctl[4];                        // [0] staged tickets, [1] resolved tickets
+    constexpr uint32_t NB = 4;                         // batches of records the stager keeps in LDS for the resolver (> NS)
+    __shared__ __attribute__((aligned(16))) u32x4 rslots[NB][64];
     const uint32_t j = blockIdx.x;
     if (j >= c.n_jobs) return;
     const seg_job sj = c.st[j];
     if (!sj.eligible || sj.failed) return;
+    if (c.ring_bytes != (uint32_t)R) return;           // (the records were classed for another ring: leave the job to the pair kernel)
     const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const lzf_decompress_job job = c.jobs[j];
     const long long t_start = clock64();
     gu8* const out = as_global(job.out);
     const uint32_t rb = (uint32_t)(reinterpret_cast<uintptr_t>(out) & 15u);
-    gu8* const outb = out - rb;                        // outb + y = out + x
+    gu8* const outb = out - rb;
     const LZF_GLOBAL u32x4* const recs = (const LZF_GLOBAL u32x4*)c.recs + sj.rec_off;
     const uint32_t n = sj.ntok, total = sj.outb;
     const uint32_t ring_a = lds_addr(ring);
-    uint32_t fp = 0, vlo = 0, fl = rb, safe = 0;       // safe: own stores below this y are visible to own loads
-#ifdef LZF_SEG_TIME
-    long long tm_rounds = 0, tm_pre = 0, tm_flush = 0; uint32_t n_rounds = 0;
-#define SEGT(var) do { const long long t__ = clock64(); var += t__ - tm_t; tm_t = t__; } while (0)
-    long long tm_t = clock64();
-#else
-#define SEGT(var) do { } while (0)
-#endif
+    if (threadIdx.x < 4u) ctl[threadIdx.x] = 0u;
+    __syncthreads();
+    // the flags, by explicit DS instructions (a volatile pointer to ctl[] is a generic pointer to hipcc: FLAT accesses, which
+    // wait for every global load in flight as well)
+    const uint32_t ctl_a = lds_addr(ctl);
+    auto flag_get = [&](uint32_t i) -> uint32_t { uint32_t v; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(ctl_a + 4u * i) : "memory"); return __builtin_amdgcn_readfirstlane(v); };
+    auto flag_set = [&](uint32_t i, uint32_t v) { asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" ::"v"(ctl_a + 4u * i), "v"(v) : "memory"); };
+    // Wait until flag i exceeds `below`.  Bounded: a wait of ~2^22 naps (seconds; a ticket takes microseconds) can only mean a
+    // defect, so the wave gives up and raises ctl[3]; both waves then leave, the job is not marked done and the pair kernel
+    // (launched after this one) decodes it.  false = give up.
+    auto flag_wait_above = [&](uint32_t i, uint32_t below) -> bool {
+        for (uint32_t spin = 0;; ++spin) {
+            if (flag_get(i) > below) return true;
+            if ((spin & 63u) == 63u && (flag_get(3) != 0u || spin > (1u << 22))) { if (lane == 0u) flag_set(3, 1u); return false; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    };
 
-    // out[y0, y1) <- ring (biased positions)
-    auto flush_range = [&](uint32_t y0, uint32_t y1) {
-        if (y1 <= y0) return;
-        uint32_t nh = (16u - (y0 & 15u)) & 15u; if (nh > y1 - y0) nh = y1 - y0;
-        if (nh) { if (lane < nh) outb[y0 + lane] = ring[(y0 + lane) & kMask]; y0 += nh; }
-        const uint32_t ng = (y1 - y0) >> 4;
-        for (uint32_t g = lane; g < ng; g += kWave)
-            *reinterpret_cast<LZF_GLOBAL u32x4*>(outb + y0 + 16u * g) = *reinterpret_cast<const u32x4*>(&ring[(y0 + 16u * g) & kMask]);
-        y0 += ng << 4;
-        if (lane < y1 - y0) outb[y0 + lane] = ring[(y0 + lane) & kMask];
-    };
-    // ring <- out, whole granules [fp, g1)
-    auto fill_to = [&](uint32_t g1) {
-        for (uint32_t y = fp + 16u * lane; y < g1; y += 16u * kWave)
-            *reinterpret_cast<u32x4*>(&ring[y & kMask]) = *reinterpret_cast<const LZF_GLOBAL u32x4*>(outb + y);
-        if (g1 > fp) fp = g1;
-    };
     // ring[d, d + nbytes) <- ring[s, s + nbytes): source final, ranges disjoint; all lanes, 8 bytes each
     auto ring_copy = [&](uint32_t d, uint32_t s_, uint32_t nbytes) {
         const uint32_t n8 = nbytes >> 3;
@@ -766,339 +804,160 @@ __global__ __launch_bounds__(64) void lzf_seg_resolve_kernel(seg_ctx c) {
         while (pos < M_) { const uint32_t cc = av < M_ - pos ? av : M_ - pos; ring_copy(d + pos, d - off_, cc); pos += cc; av += cc; }
     };
 
-    // ---- prefetch registers: granules [pf0, pf1) of `out`, at most 4 KiB
-    u32x4 pf[4] = {u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}, u32x4{0, 0, 0, 0}};
-    uint32_t pf0 = 0, pf1 = 0;
-    uint32_t flush_to = rb;                            // the ring is final below this; written to HBM one batch later
-    u32x4 rA = u32x4{0, 0, 0, 0}, rB = u32x4{0, 0, 0, 0};
-    if (lane < n) rA = recs[lane];
-    if (64u + lane < n) rB = recs[64u + lane];
-
-    for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
-        const uint32_t nb = n - i0 < 64u ? n - i0 : 64u;
-        // Order of the memory operations of an iteration (one counter serves loads and stores, in issue order):
-        //   use what was fetched one iteration ago -> stores of the previous batch -> fetches for the next iterations -> rounds.
-        // ---- 1. the granules fetched for this batch go into the ring
-        if (pf1 > pf0) {
-            if (fp < pf0) fill_to(pf0);
-            if (fp == pf0) {
-#pragma unroll
-                for (uint32_t k = 0; k < 4u; ++k) { const uint32_t y = pf0 + 1024u * k + 16u * lane; if (y < pf1) *reinterpret_cast<u32x4*>(&ring[y & kMask]) = pf[k]; }
-                fp = pf1;
-            }
-            pf0 = pf1 = 0;
-        }
-        // ---- 2. the previous batch goes to HBM
-        if (flush_to > fl) { flush_range(fl, flush_to); fl = flush_to; }
-        // ---- 3. this batch's records; fetch the granules of the next batch and the records of the one after
-        const u32x4 r = rA;
-        rA = rB;
-        const uint32_t lo = r[0], mo = r[1], M = lane < nb ? r[2] : 0u, off = r[3] & 0xFFFFu, lvl = (r[3] >> 16) & 255u;
-        const bool coopf = ((r[3] >> 24) & kFlagCoop) != 0u;
-        const uint32_t endp = mo + M;
-        {
-            const uint32_t need0 = (__builtin_amdgcn_readlane(endp, (nb - 1u) & 63u) + rb + 15u) & ~15u;
-            if (i0 + 64u < n) {
-                const uint32_t nb1 = n - i0 - 64u < 64u ? n - i0 - 64u : 64u;
-                const uint32_t need1 = (__builtin_amdgcn_readlane(rA[1] + rA[2], (nb1 - 1u) & 63u) + rb + 15u) & ~15u;
-                const uint32_t from = fp > need0 ? fp : need0;
-                uint32_t to = need1; if (to > from + 4096u) to = from + 4096u;
-                if (to > from) {
-                    pf0 = from; pf1 = to;
-#pragma unroll
-                    for (uint32_t k = 0; k < 4u; ++k) { const uint32_t y = from + 1024u * k + 16u * lane; if (y < to) pf[k] = *reinterpret_cast<const LZF_GLOBAL u32x4*>(outb + y); }
-                }
-            }
-        }
-        rB = u32x4{0, 0, 0, 0};
-        if (i0 + 128u + lane < n) rB = recs[i0 + 128u + lane];
-        SEGT(tm_pre);
-        uint32_t a = 0;
-        while (a < nb) {
-            const uint32_t ob = __builtin_amdgcn_readlane(lo, a);
-            const uint32_t bb0 = first_lane(__ballot(lane >= a && lane < nb && endp - ob > kSpan));
-            const uint32_t b = bb0 < nb ? bb0 : nb;
-            if (b == a) {
-                // ---- a sequence larger than a sub-batch: its literals are in place; the match goes HBM -> HBM
-                const uint32_t g_mo = __builtin_amdgcn_readlane(mo, a), g_M = __builtin_amdgcn_readlane(M, a), g_off = __builtin_amdgcn_readlane(off, a);
-                const uint32_t g_lo = ob, g_end = g_mo + g_M;
-                if (fp < ((g_lo + rb + 15u) & ~15u)) fill_to((g_lo + rb + 15u) & ~15u);   // (the ring up to the sequence, for the flush below)
-                flush_range(fl, g_lo + rb);                                                 // everything in front of the sequence to HBM, byte-exact
-                wave_store_fence();
-                if (g_M) {
-                    gu8* const src = out + (g_mo - g_off);
-                    uint32_t pos = 0, av = g_off;
-                    while (pos < g_M) {               // the same doubling as ring_match, through HBM
-                        const uint32_t cc = av < g_M - pos ? av : g_M - pos;
-                        wave_copy_long(out + g_mo + pos, src, cc, lane);
-                        pos += cc; av += cc;
-                        if (pos < g_M) wave_store_fence();
-                    }
-                    wave_store_fence();
-                }
-                // the ring starts again behind the sequence (the granule that holds its last bytes is read back by the next
-                // fill; fl = ye keeps those bytes from being written twice — they are already there)
-                const uint32_t ye = g_end + rb;
-                vlo = ye & ~15u; fp = vlo; fl = ye; safe = ye; flush_to = ye;
-                a += 1u;
-                continue;
-            }
-            const bool inb = lane >= a && lane < b;
-            const uint32_t oe = __builtin_amdgcn_readlane(endp, b - 1u);
-            fill_to((oe + rb + 15u) & ~15u);
-            const uint32_t lov = (fp > (uint32_t)R && fp - (uint32_t)R > vlo) ? fp - (uint32_t)R : vlo;   // the ring is valid from here
-            const bool has = inb && M != 0u;
-            const uint32_t span = M < off ? M : off;
-            const uint32_t sy = mo - off + rb, dy = mo + rb;
-            const bool near = has && sy >= lov;
-            const bool far = has && sy + span <= lov;
-            const bool mixed = has && !near && !far;
-            const uint32_t di = dy & kMask, si = sy & kMask;
-            const bool wrap = di + M > (uint32_t)R || si + M > (uint32_t)R;
-            // ---- far sources: HBM -> ring (never overlapping: the distance exceeds a sub-batch)
-            if (__ballot(far)) {
-                if (__ballot(far && sy + span > safe)) { wave_store_fence(); safe = fl; }
-                const bool far_own = far && M <= 64u && !wrap;
-                if (far_own) put_small_glb(ring_a + di, outb + sy, M);
-                for (unsigned long long m = __ballot(far && !far_own); m; m &= m - 1ull) {
-                    const uint32_t q = (uint32_t)__builtin_ctzll(m);
-                    const uint32_t qM = __builtin_amdgcn_readlane(M, q), qs = __builtin_amdgcn_readlane(sy, q), qd = __builtin_amdgcn_readlane(dy, q);
-                    for (uint32_t i = lane; i < qM; i += kWave) ring[(qd + i) & kMask] = outb[qs + i];
-                }
-            }
-            // ---- rounds.  Lanes that move their own match with one LDS round trip: A = 4..7 bytes (two 4-byte pieces),
-            // B = 8..32 bytes (four 8-byte pieces, two-ended); both classes share the round trip.  The rest (33..64 bytes
-            // or overlapping: own doubling steps; longer, wrapping, mixed sources: the whole wave) follows in the same round.
-            const bool own = near && !coopf && !wrap && M <= 64u;
-            const bool ovl = off < M;
-            const bool fastA = own && !ovl && M < 8u, fastB = own && !ovl && M >= 8u && M <= 32u;
-            const bool slow_own = own && !fastA && !fastB;
-            const unsigned long long mA_all = __ballot(fastA), mB_all = __ballot(fastB);
-            const unsigned long long mS_all = __ballot((near || mixed) && !fastA && !fastB);
-            unsigned long long todo = mA_all | mB_all | mS_all;
-            const uint32_t sa = ring_a + si, da = ring_a + di;
-            const uint32_t o1 = M >= 16u ? 8u : M - 8u, o2 = M >= 16u ? M - 16u : 0u, o3 = M - 8u, a1 = M - 4u;
-            for (uint32_t lv = 1; todo; ++lv) {
-                const unsigned long long ml = __ballot(lvl == lv) & todo;
-                if (!ml) { if (lv > 70u) break; continue; }
-                todo &= ~ml;
-#ifdef LZF_SEG_TIME
-                ++n_rounds;
-#endif
-                const unsigned long long mA = ml & mA_all, mB = ml & mB_all, mS = ml & mS_all;
-                if (mA | mB) {
-                    uint32_t va0, va1; uint64_t vb0, vb1, vb2, vb3; unsigned long long sv;
-                    asm volatile(
-                        "s_mov_b64 %[sv], exec\n\t"
-                        "s_mov_b64 exec, %[mA]\n\t"
-                        "ds_read_b32 %[va0], %[sa]\n\t"
-                        "ds_read_b32 %[va1], %[sa1]\n\t"
-                        "s_mov_b64 exec, %[mB]\n\t"
-                        "ds_read_b64 %[vb0], %[sa]\n\t"
-                        "ds_read_b64 %[vb1], %[sb1]\n\t"
-                        "ds_read_b64 %[vb2], %[sb2]\n\t"
-                        "ds_read_b64 %[vb3], %[sb3]\n\t"
-                        "s_waitcnt lgkmcnt(0)\n\t"
-                        "ds_write_b64 %[da], %[vb0]\n\t"
-                        "ds_write_b64 %[db1], %[vb1]\n\t"
-                        "ds_write_b64 %[db2], %[vb2]\n\t"
-                        "ds_write_b64 %[db3], %[vb3]\n\t"
-                        "s_mov_b64 exec, %[mA]\n\t"
-                        "ds_write_b32 %[da], %[va0]\n\t"
-                        "ds_write_b32 %[da1], %[va1]\n\t"
-                        "s_mov_b64 exec, %[sv]\n\t"
-                        : [va0] "=&v"(va0), [va1] "=&v"(va1), [vb0] "=&v"(vb0), [vb1] "=&v"(vb1), [vb2] "=&v"(vb2), [vb3] "=&v"(vb3), [sv] "=&s"(sv)
-                        : [mA] "s"(mA), [mB] "s"(mB), [sa] "v"(sa), [sa1] "v"(sa + a1), [sb1] "v"(sa + o1), [sb2] "v"(sa + o2), [sb3] "v"(sa + o3),
-                          [da] "v"(da), [da1] "v"(da + a1), [db1] "v"(da + o1), [db2] "v"(da + o2), [db3] "v"(da + o3)
-                        : "memory");
-                }
-                if (mS) {
-                    const bool nowS = (mS >> lane) & 1ull;
-                    if (nowS && slow_own) {                       // 33..64 bytes, or overlapping: doubling steps of its own
-                        uint32_t pos = 0, av = off;
-                        while (pos < M) { const uint32_t cc = av < M - pos ? av : M - pos; put_small_lds(da + pos, sa, cc); pos += cc; av += cc; }
-                    }
-                    for (unsigned long long m = __ballot(nowS && !slow_own); m; m &= m - 1ull) {
-                        const uint32_t q = (uint32_t)__builtin_ctzll(m);
-                        const uint32_t qM = __builtin_amdgcn_readlane(M, q), qs = __builtin_amdgcn_readlane(sy, q), qd = __builtin_amdgcn_readlane(dy, q);
-                        const uint32_t qo = __builtin_amdgcn_readlane(off, q);
-                        const bool qmixed = (__ballot(mixed) >> q) & 1ull;
-                        if (qmixed) {
-                            // source partly older than the ring: byte by byte, from HBM below lov
-                            if (qs + (qo < qM ? qo : qM) > safe) { wave_store_fence(); safe = fl; }
-                            if (lane == q) {
-                                for (uint32_t i = 0; i < qM; ++i) {
-                                    const uint32_t y = qs + (qo < qM ? i % qo : i);
-                                    ring[(qd + i) & kMask] = y < lov ? (uint8_t)outb[y] : ring[y & kMask];
-                                }
-                            }
-                        } else ring_match(qd, qo, qM);
-                    }
-                }
-            }
-            SEGT(tm_rounds);
-            // ---- the sub-batch is final in the ring; it goes to HBM at the top of the next batch (or now, when much is pending)
-            flush_to = (oe + rb) & ~15u;
-            if (flush_to > fl && flush_to - fl > 8192u) { flush_range(fl, flush_to); fl = flush_to; }
-            SEGT(tm_flush);
-            a = b;
-        }
-    }
-    if (flush_to > fl) { flush_range(fl, flush_to); fl = flush_to; }
-    flush_range(fl, total + rb);
-    if (lane == 0u) {
-        c.results[j].out_len = total;
-        c.results[j].status = LZF_OK;
-        c.results[j].reserved = (uint32_t)((clock64() - t_start) >> 10);
-#ifdef LZF_SEG_TIME
-        c.st[j].pad = n_rounds;
-        c.st[j].pad2 = (uint64_t)(uint32_t)(tm_rounds >> 10) | ((uint64_t)(uint16_t)(tm_pre >> 14) << 32) | ((uint64_t)(uint16_t)(tm_flush >> 14) << 48);
-#endif
-        c.st[j].done = 1u;
-    }
-#undef SEGT
-}
-
-// =====================================================================================================================
-// resolve, as a pair of wavefronts per block: the STAGER (wave 1) does everything that is not the dependency chain — the
-// ring's granules in from `out` (literals are there), finished granules out to HBM, the few sources that are older than the
-// ring (read back from HBM), sequences larger than a sub-batch (HBM -> HBM), and per lane the LDS addresses, length class
-// and level of its match, parked in an LDS slot; the RESOLVER (wave 0) takes slot after slot and runs the rounds.
-// Tickets: the stager publishes sub-batch t with ctl[0] = t + 1 after its LDS writes; the resolver answers with
-// ctl[1] = t + 1 after its own.  LDS executes one wave's accesses in order, so a flag is never seen before the data.
-// =====================================================================================================================
-template <int R>
-__global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
-    constexpr uint32_t kMask = (uint32_t)R - 1u;
-    constexpr uint32_t kSpan = (uint32_t)R / 8u;       // output bytes one sub-batch may produce
-    constexpr uint32_t NS = 3;                         // slots: sub-batches the stager may be ahead
-    constexpr uint32_t kAhead = NS * kSpan + 64u;      // ... i.e. the fill pointer may be this far beyond a sub-batch when it is resolved
-    __shared__ __attribute__((aligned(16))) uint8_t ring[R];
-    __shared__ __attribute__((aligned(16))) u32x4 slots[NS][64];
-    __shared__ uint32_t ctl[4];                        // [0] staged tickets, [1] resolved tickets, [2] stager finished
-    const uint32_t j = blockIdx.x;
-    if (j >= c.n_jobs) return;
-    const seg_job sj = c.st[j];
-    if (!sj.eligible || sj.failed) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const lzf_decompress_job job = c.jobs[j];
-    const long long t_start = clock64();
-    gu8* const out = as_global(job.out);
-    const uint32_t rb = (uint32_t)(reinterpret_cast<uintptr_t>(out) & 15u);
-    gu8* const outb = out - rb;
-    const LZF_GLOBAL u32x4* const recs = (const LZF_GLOBAL u32x4*)c.recs + sj.rec_off;
-    const uint32_t n = sj.ntok, total = sj.outb;
-    const uint32_t ring_a = lds_addr(ring);
-    volatile uint32_t* const vctl = ctl;
-    if (threadIdx.x < 4u) ctl[threadIdx.x] = 0u;
-    __syncthreads();
-
-    // ring[d, d + nbytes) <- ring[s, s + nbytes): source final, ranges disjoint; all lanes, 8 bytes each
-    auto ring_copy = [&](uint32_t d, uint32_t s_, uint32_t nbytes) {
-        const uint32_t n8 = nbytes >> 3;
-        for (uint32_t u = lane; u < n8; u += kWave) {
-            const uint32_t sa = (s_ + 8u * u) & kMask, da = (d + 8u * u) & kMask;
-            if (sa + 8u <= (uint32_t)R && da + 8u <= (uint32_t)R) lds_st64(ring_a + da, lds_ld64u(ring_a + sa));
-            else for (uint32_t t = 0; t < 8u; ++t) ring[(da + t) & kMask] = ring[(sa + t) & kMask];
-        }
-        const uint32_t t0 = n8 << 3;
-        if (lane < nbytes - t0) ring[(d + t0 + lane) & kMask] = ring[(s_ + t0 + lane) & kMask];
-    };
-    auto ring_match = [&](uint32_t d, uint32_t off_, uint32_t M_) {
-        uint32_t pos = 0, av = off_;
-        while (pos < M_) { const uint32_t cc = av < M_ - pos ? av : M_ - pos; ring_copy(d + pos, d - off_, cc); pos += cc; av += cc; }
-    };
-
     if (role == 0u) {
         // ================================================ RESOLVER ================================================
-        for (uint32_t t = 0;; ++t) {
-            uint32_t staged;
-            for (;;) {
-                staged = vctl[0];
-                if (staged > t) break;
-                if (vctl[2]) { staged = vctl[0]; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (staged <= t) break;
-            const u32x4 d = slots[t % NS][lane];
-            // d[0] = LDS address of the source, d[1] = of the destination, d[2] = M | lvl << 16 | class << 24, d[3] = off | lanes << 16 (lane 0..)
-            const uint32_t sa = d[0], da = d[1], M = d[2] & 0xFFFFu, lvl = (d[2] >> 16) & 255u, cls = d[2] >> 24, off = d[3];
-            // class: 1 = A (4..7), 2 = B (8..32), 3 = C (33..64), 4 = own doubling steps (overlapping, <= 64), 5 = whole wave; 0 = nothing to do
-            const unsigned long long mA_all = __ballot(cls == 1u), mB_all = __ballot(cls == 2u), mC_all = __ballot(cls == 3u);
-            const unsigned long long mS_all = __ballot(cls >= 4u);
-            unsigned long long todo = mA_all | mB_all | mC_all | mS_all;
-            const uint32_t o1 = M >= 16u ? 8u : M - 8u, o2 = M >= 16u ? M - 16u : 0u, o3 = M - 8u, a1 = M - 4u;
-            for (uint32_t lv = 1; todo; ++lv) {
-                const unsigned long long ml = __ballot(lvl == lv) & todo;
-                if (!ml) { if (lv > 70u) break; continue; }
-                todo &= ~ml;
-                const unsigned long long mA = ml & mA_all, mB = ml & (mB_all | mC_all), mC = ml & mC_all, mS = ml & mS_all;
-                if (mA | mB) {
-                    uint32_t va0, va1; uint64_t vb0, vb1, vb2, vb3, vc0, vc1, vc2, vc3; unsigned long long sv;
-                    asm volatile(
-                        "s_mov_b64 %[sv], exec\n\t"
-                        "s_mov_b64 exec, %[mA]\n\t"
-                        "ds_read_b32 %[va0], %[sa]\n\t"
-                        "ds_read_b32 %[va1], %[sa1]\n\t"
-                        "s_mov_b64 exec, %[mB]\n\t"
-                        "ds_read_b64 %[vb0], %[sa]\n\t"
-                        "ds_read_b64 %[vb1], %[sb1]\n\t"
-                        "ds_read_b64 %[vb2], %[sb2]\n\t"
-                        "ds_read_b64 %[vb3], %[sb3]\n\t"
-                        "s_mov_b64 exec, %[mC]\n\t"
-                        "s_cbranch_execz Lnc1%=\n\t"
-                        "ds_read_b64 %[vc0], %[sa] offset:16\n\t"
-                        "ds_read_b64 %[vc1], %[sa] offset:24\n\t"
-                        "ds_read_b64 %[vc2], %[sc2]\n\t"
-                        "ds_read_b64 %[vc3], %[sc3]\n\t"
-                        "Lnc1%=:\n\t"
-                        "s_waitcnt lgkmcnt(0)\n\t"
-                        "s_cbranch_execz Lnc2%=\n\t"
-                        "ds_write_b64 %[da], %[vc0] offset:16\n\t"
-                        "ds_write_b64 %[da], %[vc1] offset:24\n\t"
-                        "ds_write_b64 %[dc2], %[vc2]\n\t"
-                        "ds_write_b64 %[dc3], %[vc3]\n\t"
-                        "Lnc2%=:\n\t"
-                        "s_mov_b64 exec, %[mB]\n\t"
-                        "ds_write_b64 %[da], %[vb0]\n\t"
-                        "ds_write_b64 %[db1], %[vb1]\n\t"
-                        "ds_write_b64 %[db2], %[vb2]\n\t"
-                        "ds_write_b64 %[db3], %[vb3]\n\t"
-                        "s_mov_b64 exec, %[mA]\n\t"
-                        "ds_write_b32 %[da], %[va0]\n\t"
-                        "ds_write_b32 %[da1], %[va1]\n\t"
-                        "s_mov_b64 exec, %[sv]\n\t"
-                        : [va0] "=&v"(va0), [va1] "=&v"(va1), [vb0] "=&v"(vb0), [vb1] "=&v"(vb1), [vb2] "=&v"(vb2), [vb3] "=&v"(vb3),
-                          [vc0] "=&v"(vc0), [vc1] "=&v"(vc1), [vc2] "=&v"(vc2), [vc3] "=&v"(vc3), [sv] "=&s"(sv)
-                        : [mA] "s"(mA), [mB] "s"(mB), [mC] "s"(mC), [sa] "v"(sa), [sa1] "v"(sa + a1), [sb1] "v"(sa + o1), [sb2] "v"(sa + o2), [sb3] "v"(sa + o3),
-                          [sc2] "v"(sa + M - 32u), [sc3] "v"(sa + M - 24u),
-                          [da] "v"(da), [da1] "v"(da + a1), [db1] "v"(da + o1), [db2] "v"(da + o2), [db3] "v"(da + o3), [dc2] "v"(da + M - 32u), [dc3] "v"(da + M - 24u)
-                        : "memory");
+#ifdef LZF_SEG_TIME
+        long long tm_wait = 0, tm_setup = 0, tm_asm = 0, tm_slow = 0, tm_t = clock64(); uint32_t n_rounds = 0;
+#define RT(var) do { const long long t__ = clock64(); var += t__ - tm_t; tm_t = t__; } while (0)
+#else
+#define RT(var) do { } while (0)
+#endif
+        uint32_t t = 0;
+        for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+            const uint32_t nb = n - i0 < 64u ? n - i0 : 64u;
+            // the batch's records are in their slot once its first ticket is published
+            RT(tm_setup);
+            if (!flag_wait_above(0, t)) break;
+            RT(tm_wait);
+            const u32x4 r = rslots[(i0 >> 6) % NB][lane];
+            const uint32_t M = r[0], dy = r[1], off = r[3];
+            const uint32_t sub = lane < nb ? (r[2] & 0xFFu) : 0xFFu, lvl = (r[2] >> 16) & 255u, cls = lane < nb ? r[2] >> 24 : 0u;
+            const uint32_t nsub = __builtin_amdgcn_readlane(r[2] & 0xFFu, (nb - 1u) & 63u) + 1u;
+            const uint32_t sa = ring_a + ((dy - off) & kMask), da = ring_a + (dy & kMask);
+            // two-ended pieces: A (4..7) = 4-byte pieces at 0 and M - 4; B1 (8..16) = 8-byte pieces at 0 and M - 8;
+            // B2 (17..32) adds 8 and M - 16; C (33..64) adds 16, 24, M - 32, M - 24
+            const uint32_t o3 = M - 8u, a1 = M - 4u;
+            const unsigned long long mA_b = __ballot(cls == 1u), m2_b = __ballot(cls >= 2u && cls <= 4u), m3_b = __ballot(cls == 3u || cls == 4u),
+                                     m4_b = __ballot(cls == 4u), mS_b = __ballot(cls == 5u || cls == 6u);
+            bool gave_up = false;
+            for (uint32_t s_i = 0; s_i < nsub; ++s_i, ++t) {
+                // ---- wait for the stager's ticket
+                if (s_i) {
+                    RT(tm_setup);
+                    if (!flag_wait_above(0, t)) { gave_up = true; break; }
+                    RT(tm_wait);
                 }
-                if (mS) {
-                    const bool nowS = (mS >> lane) & 1ull;
-                    if (nowS && cls == 4u) {                      // overlapping, at most 64 bytes: doubling steps of its own
-                        uint32_t pos = 0, av = off;
-                        while (pos < M) { const uint32_t cc = av < M - pos ? av : M - pos; put_small_lds(da + pos, sa, cc); pos += cc; av += cc; }
+                const unsigned long long msub = nsub == 1u ? ~0ull : __ballot(sub == s_i);
+                unsigned long long todo = (mA_b | m2_b | mS_b) & msub;
+                for (uint32_t lv = 1; todo; ++lv) {
+                    const unsigned long long ml = __ballot(lvl == lv) & todo;
+                    if (!ml) { if (lv > 70u) break; continue; }
+                    todo &= ~ml;
+#ifdef LZF_SEG_TIME
+                    ++n_rounds;
+#endif
+                    const unsigned long long mA = ml & mA_b, m2 = ml & m2_b, m3 = ml & m3_b, m4 = ml & m4_b, mS = ml & mS_b;
+                    RT(tm_setup);
+                    if (mA | m2) {
+                        uint64_t v0, v1, v2, v3, v4, v5, v6, v7; uint32_t va0, va1; unsigned long long sv;
+                        asm volatile(
+                            "s_mov_b64 %[sv], exec\n\t"
+                            "s_mov_b64 exec, %[mA]\n\t"
+                            "ds_read_b32 %[va0], %[sa]\n\t"
+                            "ds_read_b32 %[va1], %[s1]\n\t"
+                            "s_mov_b64 exec, %[m2]\n\t"
+                            "ds_read_b64 %[v0], %[sa]\n\t"
+                            "ds_read_b64 %[v3], %[s3]\n\t"
+                            "s_mov_b64 exec, %[m3]\n\t"
+                            "s_cbranch_execz Lr3%=\n\t"
+                            "ds_read_b64 %[v1], %[sa] offset:8\n\t"
+                            "ds_read_b64 %[v2], %[s16]\n\t"
+                            "s_mov_b64 exec, %[m4]\n\t"
+                            "s_cbranch_execz Lr3%=\n\t"
+                            "ds_read_b64 %[v4], %[sa] offset:16\n\t"
+                            "ds_read_b64 %[v5], %[sa] offset:24\n\t"
+                            "ds_read_b64 %[v6], %[s32]\n\t"
+                            "ds_read_b64 %[v7], %[s32] offset:8\n\t"
+                            "Lr3%=:\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "s_mov_b64 exec, %[mA]\n\t"
+                            "ds_write_b32 %[da], %[va0]\n\t"
+                            "ds_write_b32 %[d1], %[va1]\n\t"
+                            "s_mov_b64 exec, %[m2]\n\t"
+                            "ds_write_b64 %[da], %[v0]\n\t"
+                            "ds_write_b64 %[d3], %[v3]\n\t"
+                            "s_mov_b64 exec, %[m3]\n\t"
+                            "s_cbranch_execz Lw3%=\n\t"
+                            "ds_write_b64 %[da], %[v1] offset:8\n\t"
+                            "ds_write_b64 %[d16], %[v2]\n\t"
+                            "s_mov_b64 exec, %[m4]\n\t"
+                            "s_cbranch_execz Lw3%=\n\t"
+                            "ds_write_b64 %[da], %[v4] offset:16\n\t"
+                            "ds_write_b64 %[da], %[v5] offset:24\n\t"
+                            "ds_write_b64 %[d32], %[v6]\n\t"
+                            "ds_write_b64 %[d32], %[v7] offset:8\n\t"
+                            "Lw3%=:\n\t"
+                            "s_mov_b64 exec, %[sv]\n\t"
+                            : [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3), [v4] "=&v"(v4), [v5] "=&v"(v5), [v6] "=&v"(v6), [v7] "=&v"(v7),
+                              [va0] "=&v"(va0), [va1] "=&v"(va1), [sv] "=&s"(sv)
+                            : [mA] "s"(mA), [m2] "s"(m2), [m3] "s"(m3), [m4] "s"(m4), [sa] "v"(sa), [s1] "v"(sa + a1), [s3] "v"(sa + o3), [s16] "v"(sa + M - 16u), [s32] "v"(sa + M - 32u),
+                              [da] "v"(da), [d1] "v"(da + a1), [d3] "v"(da + o3), [d16] "v"(da + M - 16u), [d32] "v"(da + M - 32u)
+                            : "memory");
                     }
-                    for (unsigned long long m = __ballot(nowS && cls == 5u); m; m &= m - 1ull) {
-                        const uint32_t q = (uint32_t)__builtin_ctzll(m);
-                        // (whole-wave matches carry their biased position in sa / da and the full length in off's slot)
-                        ring_match(__builtin_amdgcn_readlane(da, q), __builtin_amdgcn_readlane(off & 0xFFFFu, q), __builtin_amdgcn_readlane(sa, q));
+                    RT(tm_asm);
+                    if (mS) {
+                        const bool nowS = (mS >> lane) & 1ull;
+                        const bool fits = nowS && (((dy - off) & kMask) + M <= (uint32_t)R) && ((dy & kMask) + M <= (uint32_t)R);   // neither range wraps
+                        // (a) run-length matches (offset 1, 2 or 4), any length up to 512: the pattern from one read, stores only
+                        const bool rle = fits && (off == 1u || off == 2u || off == 4u) && M <= 512u;
+                        if (rle) {
+                            uint32_t w; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(sa) : "memory");
+                            if (off == 1u) w = (w & 0xFFu) * 0x01010101u; else if (off == 2u) w = (w & 0xFFFFu) * 0x00010001u;
+                            const uint64_t pat = (uint64_t)w | ((uint64_t)w << 32);
+                            if (M >= 8u) {
+                                for (uint32_t k = 0; k + 8u < M; k += 8u) lds_st64(da + k, pat);
+                                // the last piece ends exactly at M: its phase is (M - 8) mod off; off divides 8 and M - 8 - k0 ... rotate by bytes
+                                const uint32_t ph = (M - 8u) & (off - 1u);
+                                const uint64_t rot = ph ? (pat >> (8u * ph)) | (pat << (64u - 8u * ph)) : pat;
+                                lds_st64(da + M - 8u, rot);
+                            } else {
+                                lds_st32(da, w);
+                                const uint32_t ph = (M - 4u) & (off - 1u);
+                                lds_st32(da + M - 4u, ph ? (uint32_t)(pat >> (8u * ph)) : w);
+                            }
+                        }
+                        // (b) not overlapping, 65..160 bytes: 32 bytes per step, the last step two-ended
+                        const bool lng = fits && !rle && off >= M && M <= 160u;
+                        if (lng) {
+                            uint32_t k = 0;
+                            for (;;) {
+                                const uint32_t kk = k + 32u <= M ? k : M - 32u;
+                                uint64_t x0, x1, x2, x3;
+                                lds_ld64x4(sa + kk, sa + kk + 8u, sa + kk + 16u, sa + kk + 24u, x0, x1, x2, x3);
+                                lds_st64(da + kk, x0); lds_st64(da + kk + 8u, x1); lds_st64(da + kk + 16u, x2); lds_st64(da + kk + 24u, x3);
+                                if (k + 32u >= M) break;
+                                k += 32u;
+                            }
+                        }
+                        // (c) overlapping, at most 64 bytes: doubling steps of its own
+                        const bool dbl = fits && !rle && !lng && M <= 64u;
+                        if (dbl) {
+                            uint32_t pos = 0, av = off;
+                            while (pos < M) { const uint32_t cc = av < M - pos ? av : M - pos; put_small_lds(da + pos, sa, cc); pos += cc; av += cc; }
+                        }
+                        // (d) the rest, one at a time by the whole wave
+                        for (unsigned long long m = __ballot(nowS && !rle && !lng && !dbl); m; m &= m - 1ull) {
+                            const uint32_t q = (uint32_t)__builtin_ctzll(m);
+                            ring_match(__builtin_amdgcn_readlane(dy, q), __builtin_amdgcn_readlane(off, q), __builtin_amdgcn_readlane(M, q));
+                        }
+                        RT(tm_slow);
                     }
                 }
+                if (lane == 0u) flag_set(1, t + 1u);
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0u) vctl[1] = t + 1u;
+            if (gave_up) break;
         }
+#ifdef LZF_SEG_TIME
+        if (lane == 0u) { c.st[j].pad = n_rounds;
+            c.st[j].pad2 = (unsigned long long)(uint16_t)(tm_wait >> 14) | ((unsigned long long)(uint16_t)(tm_setup >> 14) << 16) | ((unsigned long long)(uint16_t)(tm_asm >> 14) << 32) | ((unsigned long long)(uint16_t)(tm_slow >> 14) << 48); }
+#endif
+#undef RT
     } else {
         // ================================================= STAGER =================================================
-        uint32_t fp = 0, vlo = 0, fl = rb, safe = 0;
-        uint32_t ticket = 0;                             // sub-batches published
-        uint32_t endq[NS];                               // biased end (rounded down to a granule) of the published sub-batches, by slot
-#pragma unroll
-        for (uint32_t i = 0; i < NS; ++i) endq[i] = rb;
+        uint32_t fp = 0, fl = rb, safe = 0;              // filled up to (granule), flushed up to, own stores visible below
+        uint32_t ticket = 0;                             // tickets published
+        static_assert(NS == 3, "the ends of the tickets in flight live in three scalars");
+        uint32_t endq0 = rb, endq1 = rb, endq2 = rb;     // biased end (rounded down to a granule) of the published tickets, by ticket % 3
         uint32_t flushed_t = 0;                          // tickets whose bytes are in HBM
         auto flush_range = [&](uint32_t y0, uint32_t y1) {
             if (y1 <= y0) return;
@@ -1118,117 +977,111 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
         // write what the resolver has finished to HBM (whole granules), in ticket order
         auto flush_resolved = [&](uint32_t upto_t) {
             while (flushed_t < upto_t) {
-                uint32_t e = endq[0];
-#pragma unroll
-                for (uint32_t i = 1; i < NS; ++i) if (flushed_t % NS == i) e = endq[i];
+                const uint32_t k3 = flushed_t % 3u;
+                const uint32_t e = k3 == 0u ? endq0 : k3 == 1u ? endq1 : endq2;
                 if (e > fl) { flush_range(fl, e); fl = e; }
                 ++flushed_t;
             }
         };
-        auto wait_resolved = [&](uint32_t t) { while (vctl[1] < t) __builtin_amdgcn_s_sleep(1); };
-
+#ifdef LZF_SEG_TIME
+        long long tm_swait = 0;
+        bool gave_up = false;
+        auto wait_resolved = [&](uint32_t tt) { const long long t0 = clock64(); if (tt && !gave_up && !flag_wait_above(1, tt - 1u)) gave_up = true; tm_swait += clock64() - t0; };
+#else
+        bool gave_up = false;
+        auto wait_resolved = [&](uint32_t tt) { if (tt && !gave_up && !flag_wait_above(1, tt - 1u)) gave_up = true; };
+#endif
         u32x4 rA = u32x4{0, 0, 0, 0}, rB = u32x4{0, 0, 0, 0};
-        if (lane < n) rA = recs[lane];
-        if (64u + lane < n) rB = recs[64u + lane];
-        for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
+        if (n) { rA = recs[lane < n ? lane : n - 1u]; rB = recs[64u + lane < n ? 64u + lane : n - 1u]; }
+        uint32_t prev_end = rb;                          // biased end of the previous sequence
+        for (uint32_t i0 = 0; i0 < n && !gave_up; i0 += 64u) {
             const uint32_t nb = n - i0 < 64u ? n - i0 : 64u;
             const u32x4 r = rA;
+            const uint32_t M = lane < nb ? r[0] : 0u, dy = r[1], off = r[3];
+            const uint32_t sub = lane < nb ? (r[2] & 0xFFu) : 0xFFu, cls = lane < nb ? r[2] >> 24 : 0u;
+            const uint32_t nsub = __builtin_amdgcn_readlane(r[2] & 0xFFu, (nb - 1u) & 63u) + 1u;
+            asm volatile("" ::: "memory");
             rA = rB;
-            rB = u32x4{0, 0, 0, 0};
-            if (i0 + 128u + lane < n) rB = recs[i0 + 128u + lane];
-            const uint32_t lo = r[0], mo = r[1], M = lane < nb ? r[2] : 0u, off = r[3] & 0xFFFFu, lvl = (r[3] >> 16) & 255u;
-            const uint32_t endp = mo + M;
-            uint32_t a = 0;
-            while (a < nb) {
-                const uint32_t ob = __builtin_amdgcn_readlane(lo, a);
-                const uint32_t bb0 = first_lane(__ballot(lane >= a && lane < nb && endp - ob > kSpan));
-                const uint32_t b = bb0 < nb ? bb0 : nb;
-                if (b == a) {
+            { const uint32_t ix = i0 + 128u + lane; rB = recs[ix < n ? ix : n - 1u]; }
+            asm volatile("" ::: "memory");
+            const uint32_t endy = dy + M;                // biased end of the sequence
+            // the records go to the resolver through LDS (slot re-use: the stager is at most NS < NB tickets, i.e. batches, ahead)
+            if (ticket >= NS) wait_resolved(ticket - NS + 1u);
+            rslots[(i0 >> 6) % NB][lane] = r;
+            for (uint32_t s_i = 0; s_i < nsub && !gave_up; ++s_i) {
+                const unsigned long long msub = __ballot(sub == s_i);
+                if (!msub) { gave_up = true; if (lane == 0u) flag_set(3, 1u); break; }      // (records that do not number their sub-batches 0, 1, 2 ...: not ours)
+                const uint32_t last = 63u - (uint32_t)__builtin_clzll(msub);
+                const uint32_t oe = __builtin_amdgcn_readlane(endy, last);      // biased end of the sub-batch
+                if (__ballot(sub == s_i && cls == 8u)) {
                     // ---- a sequence larger than a sub-batch: everything in front of it resolved and in HBM, then HBM -> HBM
-                    const uint32_t g_mo = __builtin_amdgcn_readlane(mo, a), g_M = __builtin_amdgcn_readlane(M, a), g_off = __builtin_amdgcn_readlane(off, a);
-                    const uint32_t g_lo = ob, g_end = g_mo + g_M;
+                    const uint32_t g_dy = __builtin_amdgcn_readlane(dy, last), g_M = __builtin_amdgcn_readlane(M, last), g_off = __builtin_amdgcn_readlane(off, last);
                     wait_resolved(ticket);
                     flush_resolved(ticket);
-                    if (fp < ((g_lo + rb + 15u) & ~15u)) fill_to((g_lo + rb + 15u) & ~15u);
-                    flush_range(fl, g_lo + rb);
+                    if (fp < ((prev_end + 15u) & ~15u)) fill_to((prev_end + 15u) & ~15u);
+                    flush_range(fl, prev_end); if (prev_end > fl) fl = prev_end;
                     wave_store_fence();
                     if (g_M) {
-                        gu8* const src = out + (g_mo - g_off);
+                        gu8* const src = outb + (g_dy - g_off);
                         uint32_t pos = 0, av = g_off;
-                        while (pos < g_M) {
+                        while (pos < g_M) {               // the same doubling as ring_match, through HBM
                             const uint32_t cc = av < g_M - pos ? av : g_M - pos;
-                            wave_copy_long(out + g_mo + pos, src, cc, lane);
+                            wave_copy_long(outb + g_dy + pos, src, cc, lane);
                             pos += cc; av += cc;
                             if (pos < g_M) wave_store_fence();
                         }
                         wave_store_fence();
                     }
-                    const uint32_t ye = g_end + rb;
-                    vlo = ye & ~15u; fp = vlo; fl = ye; safe = ye;
-                    a += 1u;
-                    continue;
-                }
-                // ---- sub-batch [a, b): a free slot, the ring filled, classes, sources older than the ring
-                if (ticket >= NS) { wait_resolved(ticket - NS + 1u); }
-                flush_resolved(vctl[1] < ticket ? vctl[1] : ticket);
-                const bool inb = lane >= a && lane < b;
-                const uint32_t oe = __builtin_amdgcn_readlane(endp, b - 1u);
-                fill_to((oe + rb + 15u) & ~15u);
-                // when the resolver gets here the fill pointer may be kAhead further: what the ring still holds then
-                const uint32_t fpw = fp + kAhead;
-                const uint32_t lov = (fpw > (uint32_t)R && fpw - (uint32_t)R > vlo) ? fpw - (uint32_t)R : vlo;
-                const bool has = inb && M != 0u;
-                const uint32_t span = M < off ? M : off;
-                const uint32_t sy = mo - off + rb, dy = mo + rb;
-                const bool near = has && sy >= lov;
-                const uint32_t di = dy & kMask, si = sy & kMask;
-                const bool wrap = di + M > (uint32_t)R || si + M > (uint32_t)R;
-                // sources (partly) older than that: moved here, from HBM below the flushed mark and from the ring above it
-                // (those ring bytes are older than every sub-batch in flight: final)
-                if (__ballot(has && !near)) {
-                    if (__ballot(has && !near && sy + span > fl)) { wait_resolved(ticket); flush_resolved(ticket); }
-                    if (__ballot(has && !near && (sy + span > fl ? fl : sy + span) > safe)) { wave_store_fence(); safe = fl; }
-                    const bool far_own = has && !near && sy + span <= fl && M <= 64u && !wrap && off >= M;
-                    if (far_own) put_small_glb(ring_a + di, outb + sy, M);
-                    for (unsigned long long m = __ballot(has && !near && !far_own); m; m &= m - 1ull) {
-                        const uint32_t q = (uint32_t)__builtin_ctzll(m);
-                        const uint32_t qM = __builtin_amdgcn_readlane(M, q), qs = __builtin_amdgcn_readlane(sy, q), qd = __builtin_amdgcn_readlane(dy, q);
-                        const uint32_t qo = __builtin_amdgcn_readlane(off, q);
-                        if (lane == q) {
-                            for (uint32_t i = 0; i < qM; ++i) {
-                                const uint32_t y = qs + (qo < qM ? i % qo : i);
-                                ring[(qd + i) & kMask] = y < fl ? (uint8_t)outb[y] : ring[y & kMask];
+                    // the ring's history is read back from HBM: [oe - (R - fetch-ahead), oe), granules
+                    fl = oe; safe = oe;
+                    {
+                        const uint32_t keep = (uint32_t)R - (NS * kSpan + 128u);
+                        const uint32_t g1 = (oe + 15u) & ~15u;
+                        fp = g1 > keep ? (g1 - keep) & ~15u : 0u;
+                        // (the last granule may hold bytes of the next sequence: they are in `out` already when literals, holes otherwise)
+                        fill_to(g1);
+                    }
+                } else {
+                    // ---- sub-batch: the ring filled, the sources older than the ring moved in
+                    if (ticket >= NS) wait_resolved(ticket - NS + 1u);
+                    { const uint32_t rs = flag_get(1); flush_resolved(rs < ticket ? rs : ticket); }
+                    fill_to((oe + 15u) & ~15u);
+                    const bool old = sub == s_i && cls == 7u;
+                    if (__ballot(old)) {
+                        const uint32_t span = M < off ? M : off;
+                        const uint32_t sy = dy - off;
+                        if (__ballot(old && sy + span > fl)) { wait_resolved(ticket); flush_resolved(ticket); }
+                        if (__ballot(old && (sy + span > fl ? fl : sy + span) > safe)) { wave_store_fence(); safe = fl; }
+                        const uint32_t di = dy & kMask;
+                        const bool own = old && sy + span <= fl && M <= 64u && off >= M && di + M <= (uint32_t)R;
+                        if (own) put_small_glb(ring_a + di, outb + sy, M);
+                        for (unsigned long long m = __ballot(old && !own); m; m &= m - 1ull) {
+                            const uint32_t q = (uint32_t)__builtin_ctzll(m);
+                            const uint32_t qM = __builtin_amdgcn_readlane(M, q), qs = __builtin_amdgcn_readlane(sy, q), qd = __builtin_amdgcn_readlane(dy, q);
+                            const uint32_t qo = __builtin_amdgcn_readlane(off, q);
+                            if (lane == q) {
+                                for (uint32_t i = 0; i < qM; ++i) {
+                                    const uint32_t y = qs + (qo < qM ? i % qo : i);
+                                    ring[(qd + i) & kMask] = y < fl ? (uint8_t)outb[y] : ring[y & kMask];
+                                }
                             }
                         }
                     }
                 }
-                uint32_t cls = 0;
-                if (near) {
-                    if (M > 64u || wrap) cls = 5u;
-                    else if (off < M) cls = 4u;
-                    else cls = M < 8u ? 1u : M <= 32u ? 2u : 3u;
-                }
-                u32x4 d;
-                d[0] = cls == 5u ? M : ring_a + si;          // whole-wave matches: length / biased destination / offset
-                d[1] = cls == 5u ? dy : ring_a + di;
-                d[2] = (M & 0xFFFFu) | (lvl << 16) | (cls << 24);
-                d[3] = off;
-                slots[ticket % NS][lane] = d;
-                const uint32_t eg = (oe + rb) & ~15u;
-#pragma unroll
-                for (uint32_t i = 0; i < NS; ++i) if (ticket % NS == i) endq[i] = eg;
+                const uint32_t eg = oe & ~15u;
+                { const uint32_t k3 = ticket % 3u; if (k3 == 0u) endq0 = eg; else if (k3 == 1u) endq1 = eg; else endq2 = eg; }
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 ++ticket;
-                if (lane == 0u) vctl[0] = ticket;
-                a = b;
+                if (lane == 0u) flag_set(0, ticket);
+                prev_end = oe;
             }
         }
         wait_resolved(ticket);
         flush_resolved(ticket);
         flush_range(fl, total + rb);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+
         if (lane == 0u) {
-            vctl[2] = 1u;
             c.results[j].out_len = total;
             c.results[j].status = LZF_OK;
             c.results[j].reserved = (uint32_t)((clock64() - t_start) >> 10);
@@ -1239,9 +1092,5 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
 template __global__ void lzf_seg_resolve_pair_kernel<32768>(seg_ctx);
 template __global__ void lzf_seg_resolve_pair_kernel<65536>(seg_ctx);
 template __global__ void lzf_seg_resolve_pair_kernel<131072>(seg_ctx);
-
-template __global__ void lzf_seg_resolve_kernel<32768>(seg_ctx);
-template __global__ void lzf_seg_resolve_kernel<65536>(seg_ctx);
-template __global__ void lzf_seg_resolve_kernel<131072>(seg_ctx);
 
 }  // namespace lzf

@@ -166,10 +166,12 @@ def _analysis_env(**kw):
 
 
 @pytest.mark.parametrize("variant", ["auto", "wave", "staged16", "staged32", "direct4w", "win512", "win1024", "paired16", "paired24", "paired48", "paired256",
-                                     "v6l256", "ordered"])
+                                     "v6l256", "seg", "ordered"])
 def test_every_decompress_kernel_generation(variant):
     """Every kernel generation kept in the analysis library (and every ring/region geometry) implements the same contract.
-    "ordered": the longest-first launch order that large batches get, forced on for these small ones."""
+    "ordered": the longest-first launch order that large batches get, forced on for these small ones.
+    "seg": the segmented pipeline (one block decoded by many wavefronts) with its size window opened to every input — small
+    blocks, handcrafted streams; malformed, prefix and existing-output jobs take its hand-over to the pair kernel."""
     import subprocess, sys
     env = _analysis_env(LZF_DECOMPRESS_KERNEL=variant) if variant != "ordered" else _analysis_env(LZF_DECOMPRESS_ORDER="always")
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "variant_check.py")], env=env,
@@ -214,6 +216,80 @@ def test_product_dispatch_every_batch_size_class():
         dec = gpu_decompress([dict(input=c, limit=len(b), out_cap=len(b) + len(c) + 64) for b, c in ok])
         for (b, c), (rc, d) in zip(ok, dec):
             assert rc == 0 and d == b
+
+
+def _seg_mixed_items(rng):
+    """Blocks for the segmented pipeline (compressed size >= 64 KiB puts a job in its window) next to jobs it must leave to
+    the pair kernel.  Returns (items for gpu_decompress, expected (status, bytes) from the oracle)."""
+    mib = 1 << 20
+    gens = [synth.gen_text_zipf, synth.gen_markup, synth.gen_exe, synth.gen_records, synth.gen_walk16, synth.gen_log]
+    raws = [g(100 + i, mib + 777 * i).tobytes() for i, g in enumerate(gens)]
+    raws.append(synth.silesia_mix(0, 3 * mib).tobytes())                                  # a 3 MiB text block
+    raws.append(bytes(2 * mib) + synth.gen_text_zipf(7, 300000).tobytes() + bytes(mib))     # zero runs of MiBs: sequences larger than any sub-batch
+    raws.append((synth.repeat256(700000).tobytes() + synth.gen_random(3, 200000).tobytes()) * 2)   # 64 KiB+ overlapping matches, 200 KB literal runs
+    raws.append(synth.gen_random(9, 300000).tobytes() + synth.gen_text_zipf(8, 400000).tobytes())  # one 300 KB literal run, then text
+    items, exp = [], []
+    for d in raws:
+        c = o.compress2(d)[1]
+        items.append(dict(input=c, limit=len(d), out_cap=len(d) + len(c) + 64)); exp.append((0, d))
+    # handcrafted streams (dense tokens, long overlapping matches, tiny offsets), large enough for the window
+    for seed, nseq, prof in [(21, 60000, "dense"), (22, 30000, "mixed"), (23, 3000, "long"), (24, 20000, "rle")]:
+        blk, out = vectors.synth_stream(seed, nseq, prof)
+        items.append(dict(input=blk, limit=len(out), out_cap=len(out) + len(blk) + 64)); exp.append((0, out))
+    d0 = raws[0]; c0 = o.compress2(d0)[1]
+    # the same block with too little room, with a limit one byte short, and damaged: pair-kernel statuses
+    for kw in (dict(limit=len(d0), out_cap=len(d0) - 5000), dict(limit=len(d0) - 1, out_cap=len(d0) + len(c0) + 64)):
+        items.append(dict(input=c0, **kw)); exp.append(o.decompress_raw(c0, limit=kw["limit"], cap=kw["out_cap"]))
+    for k in range(6):
+        b = bytearray(c0)
+        for _ in range(1 + k):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        if k >= 4:
+            del b[int(rng.integers(len(b) // 2, len(b))):]
+        m = bytes(b)
+        items.append(dict(input=m, limit=len(d0), out_cap=len(d0) + len(m) + 64)); exp.append(o.decompress_raw(m, limit=len(d0), cap=len(d0) + len(m) + 64))
+    # prefix / existing output (not the pipeline's), and a block below its window
+    dic, payload = d0[:60000], d0[60000:]
+    cp = o.compress2(dic + payload, cursor=len(dic))[1]
+    items.append(dict(input=cp, prefix=dic, limit=len(payload))); exp.append((0, payload))
+    items.append(dict(input=cp, existing=dic, limit=len(d0))); exp.append((0, d0))
+    small = d0[:50000]
+    items.append(dict(input=o.compress2(small)[1], limit=len(small))); exp.append((0, small))
+    return items, exp
+
+
+def test_segmented_pipeline_mixed_batch():
+    """lzf_decompress_batch sends batches of up to three blocks per CU through the segmented pipeline (a block decoded by
+    many wavefronts: speculative chunk parse, seam, tile scan, records + literals, levels, stager / resolver pair) and hands
+    what the pipeline does not finish — every DecodeError, capacity, prefix / existing output, blocks below 64 KiB of input —
+    to the pair kernel.  One batch with all of it: statuses and bytes as the oracle's."""
+    rng = np.random.default_rng(77)
+    items, exp = _seg_mixed_items(rng)
+    res = gpu_decompress(items)
+    nerr = 0
+    for i, ((rc, out), (erc, eout)) in enumerate(zip(res, exp)):
+        assert rc == erc, (i, rc, erc)
+        if rc == 0:
+            assert out == eout, i
+        else:
+            nerr += 1
+    assert nerr >= 2
+
+
+@pytest.mark.parametrize("copies", [25, 55])
+def test_segmented_pipeline_smaller_rings(copies):
+    """More than one block per CU: 64 KiB (up to two per CU) and 32 KiB rings (beyond), where the oldest sources are read
+    back from HBM by the stager.  The 1 MiB blocks of a text / records / binary mix, `copies` times."""
+    mib = 1 << 20
+    base = [synth.silesia_mix(k * 4 * mib, k * 4 * mib + mib).tobytes() for k in (0, 3, 15, 17, 25, 29, 37, 44, 47)] + \
+           [synth.gen_records(5, mib).tobytes(), synth.gen_exe(6, mib).tobytes(), synth.gen_log(7, mib).tobytes()]
+    comps = [o.compress2(d) for d in base]
+    pairs = [(d, c) for d, (rc, c) in zip(base, comps) if rc == 0]
+    items = [dict(input=c, limit=len(d), out_cap=len(d) + len(c) + 64) for d, c in pairs] * copies
+    assert 256 < len(items) <= 768
+    res = gpu_decompress(items)
+    for k, (rc, out) in enumerate(res):
+        assert rc == 0 and out == pairs[k % len(pairs)][0], k
 
 
 def test_oversized_but_ok_literals_and_out_capacity():

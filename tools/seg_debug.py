@@ -147,6 +147,9 @@ def run(blocks, min_in, upto, verbose=True):
             exp = np.zeros((len(toks), 4), np.uint32)
             for k, (pos, L, M, off, src) in enumerate(toks):
                 exp[k] = (lo, lo + L, M, off); lo += L + M
+            if upto >= 7:       # the levels stage rewrites a record as {M, biased destination, sub | level << 16 | class << 24, off}
+                rbias = (int(dout.data_ptr()) + int(out_off[i])) & 15
+                r = np.stack([r[:, 1] - rbias - (exp[:, 1] - exp[:, 0]), r[:, 1] - rbias, r[:, 0], (r[:, 3] & 0xFFFF) | (r[:, 2] & 0xFFFF0000)], axis=1).astype(np.uint32)
             bad = np.nonzero((r[:, :3] != exp[:, :3]).any(axis=1) | ((r[:, 3] & 0xFFFF) != exp[:, 3]))[0]
             if len(bad):
                 k = int(bad[0])
@@ -200,7 +203,7 @@ def run(blocks, min_in, upto, verbose=True):
             extra = ""
             if int(s["pad"]):
                 p2 = int(s["pad2"])
-                extra = f", rounds {int(s['pad'])} ({int(s['pad']) / max(1, (len(toks) + 63) // 64):.2f}/batch), kcycles rounds {p2 & 0xFFFFFFFF} pre {((p2 >> 32) & 0xFFFF) << 4} flush+loop {((p2 >> 48) & 0xFFFF) << 4}"
+                extra = f", rounds {int(s['pad'])} ({int(s['pad']) / max(1, (len(toks) + 63) // 64):.2f}/batch), resolver kcycles: wait {(p2 & 0xFFFF) << 4} setup {((p2 >> 16) & 0xFFFF) << 4} asm rounds {((p2 >> 32) & 0xFFFF) << 4} slow paths {((p2 >> 48) & 0xFFFF) << 4}"
             print(f"  [{name}] ok (comp {len(cdat)}, {len(toks)} tokens, failed={s['failed']}, kcycles {res[i]['reserved']}{extra})")
     return ok_all
 
