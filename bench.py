@@ -159,11 +159,9 @@ def traffic_for(kernel_name, which, n_jobs):
     return (2 * tj["FETCH_SIZE_KB"] + tj["WRITE_SIZE_KB"]) * 1024.0 * n_jobs / tj["jobs"]
 
 
-def decompress_kernel_name(n_jobs):
-    """What lzf_decompress_batch launches for a batch of n_jobs (capi.hip: 8 / 64 blocks per CU are the thresholds; 256 CUs)."""
-    if n_jobs <= 2048:
-        return "lzf_decompress_paired_kernel<4096,48,640>"
-    return "lzf_decompress_paired_kernel<4096,24,384>" if n_jobs <= 16384 else "lzf_decompress_batched_kernel<4096,16,256,staged>"
+def last_decompress_launch(ffi):
+    """What the last lzf_decompress_batch of this thread launched, as the library says (lzf_last_decompress_launch)."""
+    return ffi.lib().lzf_last_decompress_launch().decode()
 
 
 def timed_launches(torch, fn, steps):
@@ -191,6 +189,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-config4", action="store_true", help="silesia workload: skip the strong-scaled configs[3] leg of the line")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -220,6 +219,20 @@ def main():
         line = run_config4(args, torch, device, ffi, dist, rank, world, dev)
     else:
         line = run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases)
+        if not args.no_config4:
+            # the one workload with a real exchange (BASELINE configs[3]), strong-scaled, as a leg of the same line: a driver
+            # run at N GPUs records the weak-scaled Silesia value and this
+            import copy, gc
+            gc.collect(); torch.cuda.empty_cache()
+            a4 = copy.copy(args); a4.steps = max(1, min(args.steps, 3)); a4.warmup = 1; a4.no_cpu = True
+            l4 = run_config4(a4, torch, device, ffi, dist, rank, world, dev)
+            if rank == 0:
+                line["config4"] = {"value": l4["value"], "unit": l4["unit"], "scaling": "strong", "steps": a4.steps, "ms_per_step": l4["ms_per_step"],
+                                   "compress_ms": l4["roofline"]["kernel_ms"], "gather_ms": l4["config"]["gather_ms"],
+                                   "wire_bytes_in_per_rank": l4["config"]["wire_bytes_in_per_rank"], "frame_bytes": l4["config"]["frame_bytes"],
+                                   "n_ranks_seen_by_rccl": l4["config"]["n_ranks_seen_by_rccl"], "blocks": l4["config"]["blocks"],
+                                   "verified_against_oracle_prefix": l4["config"]["verified_against_oracle_prefix"],
+                                   "content_checksum": l4["config"]["content_checksum"]}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist:
@@ -345,6 +358,7 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t1
     d_kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    kname_main = last_decompress_launch(ffi)
 
     dres = device.results_to_host(d_dres, nk)
     assert np.all(dres["status"] == ffi.OK), f"decompress statuses: {np.unique(dres['status'])}"
@@ -361,11 +375,34 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
     total_bytes, kernel_bytes = float(tot[0]), float(tot[1])
 
     d_bytes = float(lens[kidx].sum() + clen[kidx].sum())               # C + N of the kernel's jobs
-    kname = decompress_kernel_name(nk)
+    kname = kname_main
     d_traffic = traffic_for(kname, "decompress", nk)
     c_traffic = traffic_for("lzf_compress_compact_kernel<false>", "compress", nblk)
     d_achieved = d_bytes / (d_kernel_ms * 1e-3) / 1e9
     c_achieved = c_bytes / (c_kernel_ms * 1e-3) / 1e9
+
+    # ------------------------------------------------------------------ batch-size sweep of the same call (this rank's first copies)
+    sweep = None
+    if rank == 0:
+        sweep = {}
+        per_copy = max(1, nk // copies)
+        for c_n in (1, 4, 20):
+            m = min(nk, per_copy * c_n)
+            if m == nk:
+                continue
+            ts = []
+            for _ in range(6):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(); device.decompress_batch(d_dj, d_dres, m); b.record()
+                torch.cuda.synchronize()
+                ts.append(a.elapsed_time(b))
+            r_ = device.results_to_host(d_dres, m)
+            assert np.all(r_["status"] == ffi.OK) and np.array_equal(r_["out_len"], lens[kidx[:m]])
+            ms = float(sorted(ts[1:])[2])
+            sweep[str(m)] = {"ms": round(ms, 3), "gibs": round(float(lens[kidx[:m]].sum()) / (ms * 1e-3) / 2**30, 2), "launch": last_decompress_launch(ffi)}
+        sweep[str(nk)] = {"ms": round(d_kernel_ms, 3), "gibs": round(float(lens[kidx].sum()) / (d_kernel_ms * 1e-3) / 2**30, 2), "launch": kname_main}
+        if not args.no_verify:
+            assert torch.equal(dec, src), "decoded bytes differ from the source after the batch sweep"
 
     # ------------------------------------------------------------------ CPU baseline + host-buffer end to end (rank 0, N = 1)
     cpu = e2e = None
@@ -408,6 +445,9 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
                                   "achieved": round(c_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(c_achieved / HBM_PEAK_GBS, 5), "traffic": c_traffic,
                                   "algorithmic_bytes_per_launch": c_bytes, "kernel_ms": round(c_kernel_ms, 3)}},
+        # the same call at smaller batch sizes (compressed blocks of the first 1 / 4 / 20 copies; kernel time by HIP events,
+        # median of 5): up to 768 blocks go through the segmented pipeline, a block decoded by many wavefronts
+        "batch_sweep": sweep,
         "cpu_baseline": cpu,
         "end_to_end": e2e,
     }
@@ -501,15 +541,17 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
     state = {}
     header = lzdist.frame_header(content_checksum=False, block_size=BS)
 
-    kev = []
+    kev, gev = [], []
 
     def step():
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a, b, c2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         device.compress_batch(d_cj, d_cres, nloc, ffi.KINDS_U32 | ffi.KINDS_U32_FRESH_ONLY)
         b.record()
         kev.append((a, b))
         state["frame_len"], state["comp_total"] = lzdist.gather_frame_device(d_cres, comp, src, BS, nloc, nblk_all, frame, dist, rank, world, device, header)
+        c2.record()
+        gev.append((b, c2))
 
     for _ in range(args.warmup):
         step()
@@ -517,7 +559,7 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
-    kev.clear()
+    kev.clear(); gev.clear()
     t1 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -531,6 +573,15 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed_max = float(t[0])
     k_ms = sum(a.elapsed_time(b) for a, b in kev) / max(len(kev), 1)      # the compress call of this rank (cost probe + kernel), HIP events
+    g_ms = sum(a.elapsed_time(b) for a, b in gev) / max(len(gev), 1)      # size-table all-gather + packing + segment exchange + header / EndMark
+    # what the reference's default (content_checksum: true) would add: XXH32 does not compose across ranks, so it is one serial
+    # chain over the whole stream on one host thread — timed here on a 256 MiB sample, outside the timed region
+    xx = None
+    if rank == 0:
+        sample = src[: min(src.numel(), 256 << 20)].cpu().numpy().tobytes()
+        tx = time.perf_counter(); ffi.lib().lzf_xxh32(sample, len(sample), 0); tx = time.perf_counter() - tx
+        xx = {"in_timed_region": False, "host_xxh32_gb_per_s": round(len(sample) / tx / 1e9, 2),
+              "serial_ms_for_the_stream": round(float(nblk_all) * BS / (len(sample) / tx) * 1e3, 1)}
     # ---- check: the frame's head == the oracle's frame of the same first blocks (rank 0 holds them)
     verified = None
     if rank == 0 and not args.no_verify:
@@ -572,7 +623,8 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
                                "payload all-gather and frame assembly inside the timed region; lz4 ratio %.2f" %
                                (nblk_all, total_bytes / 2**30, total_bytes / max(state["comp_total"], 1)),
                    "blocks": nblk_all, "block_size": BS, "parallelism": f"block ranges x{world}, all-gather over RCCL",
-                   "frame_bytes": int(state["frame_len"]), "wire_bytes_in_per_rank": int(wire), "verified_against_oracle_prefix": verified},
+                   "frame_bytes": int(state["frame_len"]), "wire_bytes_in_per_rank": int(wire), "verified_against_oracle_prefix": verified,
+                   "gather_ms": round(g_ms, 3), "n_ranks_seen_by_rccl": (dist.get_world_size() if dist else 0), "content_checksum": xx},
         "roofline": {"bound": "hbm", "kernel": "lzf_compress_compact_kernel<false>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_for("lzf_compress_compact_kernel<false>", "compress", nloc),
                      "algorithmic_bytes_per_launch": alg, "kernel_ms": round(k_ms, 4)},

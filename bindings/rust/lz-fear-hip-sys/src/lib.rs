@@ -67,6 +67,15 @@ pub struct lzf_chain_step {
     pub block_maxsize: u64,
 }
 
+/// CompressionSettings + content size (lzfear_frame.h; src/framed/compress.rs:36-55)
+#[repr(C)] pub struct lzf_settings {
+    pub independent_blocks: i32, pub block_checksums: i32, pub content_checksum: i32, pub has_dictionary_id: i32,
+    pub block_size: u64, pub dictionary: *const u8, pub dictionary_len: u64, pub dictionary_id: u32, pub has_content_size: i32,
+    pub content_size: u64,
+}
+/// `writer.write_all(data)`: 0 = Ok(()), anything else = the writer's error
+pub type lzf_write_all_fn = Option<unsafe extern "C" fn(ctx: *mut c_void, data: *const u8, len: usize) -> c_int>;
+#[repr(C)] pub struct lzf_frame_writer { _private: [u8; 0] }
 extern "C" {
     pub fn lzf_abi_version() -> c_int;
     pub fn lzf_last_error() -> *const c_char;
@@ -87,6 +96,19 @@ extern "C" {
                            hip_stream: *mut c_void) -> c_int;
     pub fn lzf_copy_ranges(d_src: *const *const u8, d_dst: *const *mut u8, d_len: *const u64, n: u32, max_len: u64, hip_stream: *mut c_void) -> c_int;
     pub fn lzf_xxh32_batch_host(ptrs: *const *const u8, lens: *const u64, out: *mut u32, n: u32) -> c_int;
+    pub fn lzf_last_decompress_launch() -> *const c_char;
+    // EncoderTable::replace / ::offset on host tables (src/raw/compress/mod.rs:64-74, :88-99)
+    pub fn lzf_table_replace_host(table: *mut c_void, table_kind: u32, input: *const u8, input_len: u64, pos: u64, previous: *mut u64) -> c_int;
+    pub fn lzf_table_offset_host(table: *mut c_void, table_kind: u32, add: u64) -> c_int;
+    // compress2 for any writer (mod.rs:165-166): the reference's write calls replayed into `write_all`
+    pub fn lzf_compress2_host_writer(input: *const u8, input_len: u64, cursor: u64, table: *mut c_void, table_kind: u32,
+                                     write_all: lzf_write_all_fn, ctx: *mut c_void, writer_error: *mut c_int) -> c_int;
+    // streaming frame writer (src/framed/compress.rs:138-157, :221-276)
+    pub fn lzf_frame_writer_new(s: *const lzf_settings, write_all: lzf_write_all_fn, ctx: *mut c_void, blocks_per_launch: u32, w: *mut *mut lzf_frame_writer) -> c_int;
+    pub fn lzf_frame_writer_write(w: *mut lzf_frame_writer, data: *const u8, len: usize) -> c_int;
+    pub fn lzf_frame_writer_finish(w: *mut lzf_frame_writer) -> c_int;
+    pub fn lzf_frame_writer_sink_error(w: *const lzf_frame_writer) -> c_int;
+    pub fn lzf_frame_writer_free(w: *mut lzf_frame_writer);
     // lzfear_frame.h: the block-by-block reader (LZ4FrameReader::new + decode_block) and the staging controls
     pub fn lzf_frame_reader_new(input: *const u8, in_len: usize, r: *mut *mut lzf_frame_reader) -> c_int;
     pub fn lzf_frame_reader_free(r: *mut lzf_frame_reader);

@@ -4,12 +4,22 @@ pub mod raw {
     use std::io::{self, ErrorKind, Write};
     pub use lz_fear::raw::DecodeError; // src/raw/decompress.rs:7-17
 
-    /// The two table types the kernels know (`trait EncoderTable`, src/raw/compress/mod.rs:19-25).
-    pub trait GpuTable: Default + Clone {
-        const KIND: u32;
+    /// `trait EncoderTable` (src/raw/compress/mod.rs:19-25) — all three methods — for the two table types the kernels know.
+    pub trait EncoderTable {
         fn payload_size_limit() -> usize;
+        fn replace(&mut self, input: &[u8], offset: usize) -> usize;
+        fn offset(&mut self, offset: usize);
+    }
+    /// What the C ABI needs on top of the trait: the table's kind and its address.
+    pub trait GpuTable: EncoderTable + Default + Clone {
+        const KIND: u32;
         fn as_mut_ptr(&mut self) -> *mut std::ffi::c_void;
-        fn offset(&mut self, n: usize);
+    }
+    fn replace_via_abi(table: *mut std::ffi::c_void, kind: u32, input: &[u8], offset: usize) -> usize {
+        let mut prev = 0u64;
+        let rc = unsafe { sys::lzf_table_replace_host(table, kind, input.as_ptr(), input.len() as u64, offset as u64, &mut prev) };
+        assert_eq!(rc, sys::LZF_OK, "EncoderTable contract violated"); // mod.rs:67 / :92
+        prev as usize
     }
     #[repr(transparent)]
     pub struct U32Table(Box<sys::lzf_u32_table>);
@@ -19,36 +29,51 @@ pub mod raw {
     impl Default for U16Table { fn default() -> Self { U16Table(Box::new(sys::lzf_u16_table { dict: [0; 8192], offset: 0 })) } }
     impl Clone for U32Table { fn clone(&self) -> Self { U32Table(Box::new(sys::lzf_u32_table { dict: self.0.dict, offset: self.0.offset })) } }
     impl Clone for U16Table { fn clone(&self) -> Self { U16Table(Box::new(sys::lzf_u16_table { dict: self.0.dict, offset: self.0.offset })) } }
+    impl EncoderTable for U32Table {
+        fn payload_size_limit() -> usize { u32::MAX as usize } // mod.rs:75
+        fn replace(&mut self, input: &[u8], offset: usize) -> usize { replace_via_abi(self.as_mut_ptr(), sys::LZF_TABLE_U32, input, offset) } // mod.rs:64-71
+        fn offset(&mut self, n: usize) { self.0.offset += n as u64 } // mod.rs:72-74
+    }
+    impl EncoderTable for U16Table {
+        fn payload_size_limit() -> usize { u16::MAX as usize } // mod.rs:100
+        fn replace(&mut self, input: &[u8], offset: usize) -> usize { replace_via_abi(self.as_mut_ptr(), sys::LZF_TABLE_U16, input, offset) } // mod.rs:88-96
+        fn offset(&mut self, n: usize) { self.0.offset += n as u64 } // mod.rs:97-99
+    }
     impl GpuTable for U32Table {
         const KIND: u32 = sys::LZF_TABLE_U32;
-        fn payload_size_limit() -> usize { u32::MAX as usize } // mod.rs:75
         fn as_mut_ptr(&mut self) -> *mut std::ffi::c_void { &mut *self.0 as *mut _ as *mut _ }
-        fn offset(&mut self, n: usize) { self.0.offset += n as u64 } // mod.rs:72-74
     }
     impl GpuTable for U16Table {
         const KIND: u32 = sys::LZF_TABLE_U16;
-        fn payload_size_limit() -> usize { u16::MAX as usize } // mod.rs:100
         fn as_mut_ptr(&mut self) -> *mut std::ffi::c_void { &mut *self.0 as *mut _ as *mut _ }
-        fn offset(&mut self, n: usize) { self.0.offset += n as u64 } // mod.rs:97-99
     }
 
-    /// `raw::compress2` (src/raw/compress/mod.rs:165-166).  `cap` = what the writer can still take
-    /// (the frame layer passes the payload length, src/framed/compress.rs:242; `usize::MAX` for a Vec).
-    pub fn compress2<W: Write, T: GpuTable>(input: &[u8], cursor: usize, table: &mut T, mut writer: W, cap: usize) -> io::Result<()> {
+    /// `raw::compress2` with the reference's signature (src/raw/compress/mod.rs:165-166): any `W: Write`, no capacity
+    /// argument.  The block is compressed on the device against LZ4's worst-case bound; lzf_compress2_host_writer then
+    /// replays the reference's own write calls (token, length tail, literals, offset, length tail: mod.rs:150-163,
+    /// :243-260) into `writer` through the trampoline below and stops at the first call the writer refuses — the error
+    /// returned is the writer's own, and `table` is left as the reference leaves it at that point.
+    ///
+    /// One job per call = one block at single-block latency (hundreds of ms for 4 MiB): a port of `src/framed` must call
+    /// the `_many` / batch entry points (lzf_frame_compress_many, lzf_frame_writer_*), never this wrapper in a loop.
+    pub fn compress2<W: Write, T: GpuTable>(input: &[u8], cursor: usize, table: &mut T, mut writer: W) -> io::Result<()> {
         assert!(input.len() <= T::payload_size_limit()); // mod.rs:167
-        let mut out = vec![0u8; cap.min(input.len() + input.len() / 255 + 16)];
-        let job = sys::lzf_compress_job {
-            input: input.as_ptr(), input_len: input.len() as u64, cursor: cursor as u64,
-            out: out.as_mut_ptr(), out_cap: out.len() as u64,
-            table: table.as_mut_ptr(), table_kind: T::KIND, flags: 0,
+        struct Sink<'a> { w: &'a mut dyn Write, err: Option<io::Error> }
+        unsafe extern "C" fn write_all(ctx: *mut std::ffi::c_void, data: *const u8, len: usize) -> i32 {
+            let s = &mut *(ctx as *mut Sink);
+            match s.w.write_all(std::slice::from_raw_parts(data, len)) { Ok(()) => 0, Err(e) => { s.err = Some(e); 1 } }
+        }
+        let mut sink = Sink { w: &mut writer, err: None };
+        let mut werr = 0i32;
+        let rc = unsafe {
+            sys::lzf_compress2_host_writer(input.as_ptr(), input.len() as u64, cursor as u64, table.as_mut_ptr(), T::KIND,
+                                           Some(write_all), &mut sink as *mut _ as *mut _, &mut werr)
         };
-        let mut res = sys::lzf_job_result::default();
-        let rc = unsafe { sys::lzf_compress_batch_host(&job, &mut res, 1) };
-        if rc != 0 { return Err(io::Error::new(ErrorKind::Other, "lzfear_hip: no device / HIP error")); }
-        match res.status {
-            sys::LZF_OK => writer.write_all(&out[..res.out_len as usize]),
-            sys::LZF_OUTPUT_FULL => Err(ErrorKind::ConnectionAborted.into()), // NoPartialWrites, framed/compress.rs:300
-            _ => panic!("EncoderTable contract violated"), // mod.rs:67
+        match rc {
+            sys::LZF_OK => Ok(()),
+            sys::LZF_OUTPUT_FULL => Err(sink.err.take().unwrap_or_else(|| ErrorKind::ConnectionAborted.into())), // e.g. NoPartialWrites, framed/compress.rs:300
+            sys::LZF_CONTRACT => panic!("EncoderTable contract violated"), // mod.rs:67
+            _ => Err(io::Error::new(ErrorKind::Other, "lzfear_hip: no device / HIP error")),
         }
     }
 

@@ -122,6 +122,26 @@ int lzf_frame_reader_decode_block(lzf_frame_reader* r, const uint8_t* dict, size
 int lzf_frame_reader_finished(const lzf_frame_reader* r);
 size_t lzf_frame_reader_consumed(const lzf_frame_reader* r);                     /* bytes of `in` read so far */
 
+/* Streaming frame WRITER: CompressionSettings::compress / compress_with_size_unchecked (src/framed/compress.rs:138-157) for a
+ * caller that feeds the stream piece by piece and takes the frame piece by piece — bounded memory, any stream length.
+ * compress_internal's loop (:221-276) reads `block_size` bytes per turn; here the bytes come through
+ * lzf_frame_writer_write in any granularity and leave through `write_all` (see lzf_compress2_host_writer), in the
+ * reference's order: header (:163-200) at the first write or at finish, per block the length word, the payload and the
+ * optional block checksum (:244-263), EndMark and content checksum (:277-281) at finish.
+ * Independent blocks: `blocks_per_launch` whole blocks (0 = 64) are buffered and compressed in one launch (with a
+ * dictionary: each block behind its own copy of it and the seeded template table, :217-220,:265-270).
+ * Linked blocks: one launch per block, the table and the last 64 KiB carried (:271-275).
+ * settings->has_content_size / content_size = compress_with_size_unchecked's argument.  The dictionary is copied.
+ * Byte-identical to lzf_frame_compress over the concatenated input.
+ * Returns LZF_OK, LZF_F_INVALID_BLOCK_SIZE / LZF_F_PANIC (new), LZF_OUTPUT_FULL when the sink refused a write (its code:
+ * lzf_frame_writer_sink_error; the writer is dead from then on), LZF_CONTRACT, or a negative LZF_E_*. */
+typedef struct lzf_frame_writer lzf_frame_writer;
+int lzf_frame_writer_new(const lzf_settings* s, lzf_write_all_fn write_all, void* ctx, uint32_t blocks_per_launch, lzf_frame_writer** w);
+int lzf_frame_writer_write(lzf_frame_writer* w, const uint8_t* data, size_t len);
+int lzf_frame_writer_finish(lzf_frame_writer* w);
+int lzf_frame_writer_sink_error(const lzf_frame_writer* w);
+void lzf_frame_writer_free(lzf_frame_writer* w);
+
 /* ---- the host side of the drivers (host_staging.h): one pinned slab, kept device scratch, worker threads ---------- */
 typedef struct lzf_frame_stats {
     uint64_t calls;                     /* *_many calls served */

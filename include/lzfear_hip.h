@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LZFEAR_ABI_VERSION 1
+#define LZFEAR_ABI_VERSION 2
 
 /* ---- per-job status (lzf_job_result.status) --------------------------------------------- */
 enum {
@@ -134,6 +134,9 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
 /* Batched raw::decompress_raw — src/raw/decompress.rs:58-138 for every job. */
 int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_results,
                          uint32_t n_jobs, void* hip_stream);
+/* Diagnostic: the kernels the calling thread's last lzf_decompress_batch launched (the batch size picks them: the
+ * segmented pipeline — one block decoded by many wavefronts — up to three blocks per CU, one workgroup per block beyond). */
+const char* lzf_last_decompress_launch(void);
 
 /* EncoderTable helpers on device tables.
  * lzf_table_seed_from_dictionary: the template-table loop of src/framed/compress.rs:202-211
@@ -186,6 +189,34 @@ int lzf_copy_ranges(const uint8_t* const* d_src, uint8_t* const* d_dst, const ui
  * place.  Used by the frame layer and by callers that have not moved their data to HBM. */
 int lzf_compress_batch_host(const lzf_compress_job* jobs, lzf_job_result* results, uint32_t n_jobs);
 int lzf_decompress_batch_host(const lzf_decompress_job* jobs, lzf_job_result* results, uint32_t n_jobs);
+/* EncoderTable::replace on a HOST table — src/raw/compress/mod.rs:19-25 (trait), :64-71 (U32Table), :88-96 (U16Table):
+ * swaps `pos + table.offset` into the slot of hash(input[pos..]) and returns the previous entry minus table.offset,
+ * saturating at 0 (stale entries read as position 0).  hash = hash_for_u32 (:40-51: 5 bytes of an 8-byte little-endian
+ * read, slot 0 when fewer than 8 bytes remain) or hash_for_u16 (:58-61).  With lzf_table_offset's host twin below this
+ * completes the trait for a crate that keeps `trait EncoderTable` and implements it on the C ABI's table structs.
+ * Returns LZF_OK, or LZF_CONTRACT where the reference panics: pos + offset beyond the table's integer range (:67 / :92),
+ * pos > input_len, or (U16) fewer than 4 bytes at pos (the slice read of :59). */
+int lzf_table_replace_host(void* table, uint32_t table_kind, const uint8_t* input, uint64_t input_len, uint64_t pos,
+                           uint64_t* previous);
+/* EncoderTable::offset on a host table (mod.rs:72-74, :97-99). */
+int lzf_table_offset_host(void* table, uint32_t table_kind, uint64_t add);
+
+/* raw::compress2 with the reference's signature for ANY writer — src/raw/compress/mod.rs:165-166:
+ *   pub fn compress2<W: Write, T: EncoderTable>(input: &[u8], cursor: usize, table: &mut T, mut writer: W)
+ * `write_all(ctx, data, len)` stands for `writer.write_all(data)`: 0 = Ok(()), any other value = the writer's error, which
+ * ends the call and is handed back in *writer_error (the Rust wrapper turns it into the io::Error again).  The block is
+ * compressed on the device against LZ4's worst-case bound, then the reference's own sequence of write calls is replayed
+ * from it — per sequence: the token byte, the literal length's tail (0xFF bytes four at a time, then one at a time, then
+ * the remainder byte: mod.rs:243-260), the literals in one call, the two offset bytes, the match length's tail
+ * (mod.rs:150-163); the final literal-only section likewise (:182-189).  A writer that refuses call k has seen exactly
+ * the calls 0..k-1, as under the reference.  `table` (host memory, may be NULL = T::default() thrown away) ends in the
+ * state the reference leaves it in: after the whole input, or — when the writer refuses — after the search of the
+ * sequence whose write was refused (the reference mutates the table before it writes a sequence, :196-218 then :236).
+ * Returns LZF_OK, LZF_OUTPUT_FULL (the writer refused), LZF_CONTRACT, or a negative library code.  Host buffers. */
+typedef int (*lzf_write_all_fn)(void* ctx, const uint8_t* data, size_t len);
+int lzf_compress2_host_writer(const uint8_t* input, uint64_t input_len, uint64_t cursor, void* table, uint32_t table_kind,
+                              lzf_write_all_fn write_all, void* ctx, int* writer_error);
+
 /* lzf_xxh32_batch over host buffers (staged to the device, hashed there; `out` is a host array). */
 int lzf_xxh32_batch_host(const uint8_t* const* ptrs, const uint64_t* lens, uint32_t* out, uint32_t n);
 

@@ -15,6 +15,7 @@
 namespace {
 
 thread_local std::string g_last_error;
+thread_local const char* g_last_decompress = "";      // what the last lzf_decompress_batch of this thread launched
 
 int fail_hip(hipError_t e, const char* what) {
     char buf[256];
@@ -174,6 +175,7 @@ extern "C" {
 
 int lzf_abi_version(void) { return LZFEAR_ABI_VERSION; }
 const char* lzf_last_error(void) { return g_last_error.c_str(); }
+const char* lzf_last_decompress_launch(void) { return g_last_decompress; }
 int lzf_device_count(void) { return ensure_device(); }
 
 // Launch order (both batch calls): a batch of more jobs than the chip holds at once runs longest job first, or the launch
@@ -254,6 +256,7 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
     const uint32_t* cperm = perm;
 #ifdef LZF_ANALYSIS
     if (forced != kVariantAuto) {
+        g_last_decompress = "analysis variant (LZF_DECOMPRESS_KERNEL)";
         rc = analysis_launch_decompress(forced, d_jobs, d_results, n_jobs, cperm, st);
         if (perm) HIP_TRY(hipFreeAsync(perm, st));
         return rc;
@@ -271,6 +274,9 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
     if (seg_on) {
         bool used = false;
         rc = seg_decompress(d_jobs, d_results, n_jobs, seg_min_in, st, &used);
+        if (used) g_last_decompress = n_jobs <= cu_count() ? "segmented: lzf_seg_resolve_pair_kernel<131072> + lzf_decompress_paired_kernel<4096,48,640>"
+                                     : n_jobs <= 2u * cu_count() ? "segmented: lzf_seg_resolve_pair_kernel<65536> + lzf_decompress_paired_kernel<4096,48,640>"
+                                                                 : "segmented: lzf_seg_resolve_pair_kernel<32768> + lzf_decompress_paired_kernel<4096,48,640>";
         if (rc != LZF_OK || used) { if (perm) HIP_TRY(hipFreeAsync(perm, st)); return rc; }
     }
     // The producer/consumer pair kernel, with 48-byte regions while every block's workgroup is resident at once (lowest
@@ -278,6 +284,8 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
     // (smaller LDS footprint, more blocks in flight); batches of more than eight times that many blocks (small blocks,
     // typically) go to the one-wave staged16 kernel, which has no per-block pipeline to fill.
     const uint32_t resident48 = 8u * cu_count();          // workgroups of the 48-byte form one device holds: 8 per CU (20 KB of LDS each)
+    g_last_decompress = n_jobs <= resident48 ? "lzf_decompress_paired_kernel<4096,48,640>" : n_jobs <= 8u * resident48 ? "lzf_decompress_paired_kernel<4096,24,384>"
+                                                                                                             : "lzf_decompress_batched_kernel<4096,16,256,staged>";
     if (n_jobs <= resident48)
         LAUNCH(k_paired48, dim3(n_jobs), dim3(128), 0, st, d_jobs, d_results, n_jobs, cperm, (const lzf::seg_job*)nullptr);
     else if (n_jobs <= 8u * resident48)
@@ -508,6 +516,115 @@ int lzf_decompress_batch_host(const lzf_decompress_job* jobs, lzf_job_result* re
     }
     HIP_TRY(sg.download(down, out_total, dout, cs));
     return LZF_OK;
+}
+
+// ---- EncoderTable on host tables (src/raw/compress/mod.rs:40-61, :64-74, :88-99) --------------------------------------
+int lzf_table_replace_host(void* table, uint32_t table_kind, const uint8_t* input, uint64_t input_len, uint64_t pos, uint64_t* previous) {
+    if (!table || (!input && input_len) || table_kind > LZF_TABLE_U16) { g_last_error = "lzf_table_replace_host: bad argument"; return LZF_E_INVALID; }
+    if (pos > input_len) return LZF_CONTRACT;                         // &input[offset..] panics
+    const uint64_t rem = input_len - pos;
+    if (table_kind == LZF_TABLE_U32) {
+        lzf_u32_table* t = static_cast<lzf_u32_table*>(table);
+        const uint64_t o = pos + t->offset;
+        if (o > 0xFFFFFFFFull || o < pos) return LZF_CONTRACT;         // :67 try_into().expect
+        uint64_t v = 0;
+        if (rem >= 8) memcpy(&v, input + pos, 8);                      // :43 input.get(..8) or 0 (little-endian host = little-endian GPU)
+        const uint32_t slot = (uint32_t)(((v << 24) * 889523592379ull) >> 52);
+        const uint32_t old = t->dict[slot];
+        t->dict[slot] = (uint32_t)o;
+        if (previous) *previous = old > t->offset ? old - t->offset : 0;
+    } else {
+        lzf_u16_table* t = static_cast<lzf_u16_table*>(table);
+        const uint64_t o = pos + t->offset;
+        if (o > 0xFFFFull || o < pos) return LZF_CONTRACT;             // :92
+        if (rem < 4) return LZF_CONTRACT;                               // :59 read_u32 on a short slice panics
+        uint32_t v; memcpy(&v, input + pos, 4);
+        const uint32_t slot = (uint32_t)(v * 2654435761u) >> 19;
+        const uint16_t old = t->dict[slot];
+        t->dict[slot] = (uint16_t)o;
+        if (previous) *previous = old > t->offset ? old - t->offset : 0;
+    }
+    return LZF_OK;
+}
+
+int lzf_table_offset_host(void* table, uint32_t table_kind, uint64_t add) {
+    if (!table || table_kind > LZF_TABLE_U16) { g_last_error = "lzf_table_offset_host: bad argument"; return LZF_E_INVALID; }
+    if (table_kind == LZF_TABLE_U32) static_cast<lzf_u32_table*>(table)->offset += add;
+    else static_cast<lzf_u16_table*>(table)->offset += add;
+    return LZF_OK;
+}
+
+// ---- compress2 for any writer: device compress against the worst-case bound, then the reference's write calls replayed ----
+int lzf_compress2_host_writer(const uint8_t* input, uint64_t input_len, uint64_t cursor, void* table, uint32_t table_kind,
+                              lzf_write_all_fn write_all, void* ctx, int* writer_error) {
+    if ((!input && input_len) || !write_all || table_kind > LZF_TABLE_U16) { g_last_error = "lzf_compress2_host_writer: bad argument"; return LZF_E_INVALID; }
+    if (writer_error) *writer_error = 0;
+    const uint64_t payload = cursor < input_len ? input_len - cursor : 0;
+    const uint64_t bound = payload + payload / 255 + 16;
+    std::vector<uint8_t> out(bound);
+    static_assert(sizeof(lzf_u32_table) == sizeof(lzf_u16_table), "one scratch copy serves both table kinds");
+    std::vector<uint8_t> t0(sizeof(lzf_u32_table), 0), t1;
+    if (table) memcpy(t0.data(), table, t0.size());                    // (the state on entry: a refused write needs a second run from it)
+    t1 = t0;
+    lzf_compress_job job{};
+    job.input = input; job.input_len = input_len; job.cursor = cursor;
+    job.out = out.data(); job.out_cap = bound; job.table = table ? t1.data() : nullptr; job.table_kind = table_kind;
+    lzf_job_result res{};
+    int rc = lzf_compress_batch_host(&job, &res, 1);
+    if (rc != LZF_OK) return rc;
+    if (res.status != LZF_OK) return res.status;                       // LZF_CONTRACT (the bound cannot be exceeded)
+    const uint8_t* p = out.data();
+    const uint8_t* const end = p + res.out_len;
+    // one call of the writer; false = refused
+    int werr = 0;
+    auto put = [&](const uint8_t* d, size_t n) -> bool { if (n == 0) return true; werr = write_all(ctx, d, n); return werr == 0; };
+    // the tail of a length (mod.rs:243-260) as it sits in the stream at q: k 0xFF bytes and the remainder byte
+    auto put_tail = [&](const uint8_t*& q) -> bool {
+        size_t k = 0; while (q[k] == 0xFF) ++k;
+        for (size_t i = 0; i < k / 4; ++i) { if (!put(q, 4)) return false; q += 4; }
+        for (size_t i = 0; i < k % 4; ++i) { if (!put(q, 1)) return false; q += 1; }
+        if (!put(q, 1)) return false;
+        q += 1;
+        return true;
+    };
+    bool refused = false;
+    const uint8_t* group = p;
+    while (p < end && !refused) {
+        group = p;
+        const uint8_t tok = *p;
+        const uint8_t* q = p + 1;
+        if (!put(p, 1)) { refused = true; break; }                      // writer.write_u8(token)
+        size_t L = tok >> 4;
+        if (L == 15) { const uint8_t* t = q; while (*t == 0xFF) { L += 255; ++t; } L += *t; if (!put_tail(q)) { refused = true; break; } }
+        if (!put(q, L)) { refused = true; break; }                      // writer.write_all(literal)
+        q += L;
+        if (q >= end) { p = q; break; }                                 // the literal-only section that ends the block (:182-189)
+        if (!put(q, 2)) { refused = true; break; }                      // write_u16::<LE>(offset)
+        q += 2;
+        if ((tok & 15) == 15) { if (!put_tail(q)) { refused = true; break; } }
+        p = q;
+    }
+    if (!refused) {
+        if (table) memcpy(table, t1.data(), t1.size());
+        return LZF_OK;
+    }
+    if (writer_error) *writer_error = werr;
+    if (table) {
+        // the table as the reference leaves it: after the search of the refused sequence, i.e. compress2 into a sink that
+        // takes everything in front of that sequence and not the sequence itself
+        const uint8_t* q = group; const uint8_t tok = *q++; size_t L = tok >> 4;
+        if (L == 15) { while (*q == 0xFF) { L += 255; ++q; } L += *q++; }
+        q += L;
+        if (q < end) { q += 2; if ((tok & 15) == 15) { while (*q == 0xFF) ++q; ++q; } }
+        const uint64_t gsize = (uint64_t)(q - group);
+        t1 = t0;
+        job.out_cap = (uint64_t)(group - out.data()) + gsize - 1;
+        job.table = t1.data();
+        rc = lzf_compress_batch_host(&job, &res, 1);
+        if (rc != LZF_OK) return rc;
+        memcpy(table, t1.data(), t1.size());
+    }
+    return LZF_OUTPUT_FULL;
 }
 
 int lzf_xxh32_batch_host(const uint8_t* const* ptrs, const uint64_t* lens, uint32_t* out, uint32_t n) {

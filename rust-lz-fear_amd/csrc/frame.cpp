@@ -1020,4 +1020,199 @@ void lzf_frame_set_memory_budget(size_t bytes) {
     g_budget = bytes;
 }
 
+// ---- streaming frame writer (compress.rs:138-157, :160-282 with the stream fed piece by piece) ------------------------------
+struct lzf_frame_writer {
+    lzf_settings s{};
+    std::vector<uint8_t> dict;
+    uint8_t bd = 0;
+    lzf_write_all_fn sink = nullptr; void* ctx = nullptr;
+    size_t bs = 0; uint32_t per_launch = 64;
+    std::vector<uint8_t> pending;          // stream bytes not compressed yet
+    std::vector<uint8_t> in_buffer;        // linked blocks: the reference's in_buffer (window ++ block), compress.rs:217-222
+    lzf_u32_table templ{}, table{};        // template_table / table (:202,:220)
+    bool seeded = false, header_done = false, dead = false, finished = false;
+    int sink_err = 0;
+    Xxh32 content{0};
+};
+
+namespace {
+int fw_put(lzf_frame_writer* w, const uint8_t* p, size_t n) {
+    if (n == 0) return LZF_OK;
+    const int e = w->sink(w->ctx, p, n);
+    if (e != 0) { w->sink_err = e; w->dead = true; return LZF_OUTPUT_FULL; }
+    return LZF_OK;
+}
+int fw_put32(lzf_frame_writer* w, uint32_t v) { uint8_t b[4]; wr32(b, v); return fw_put(w, b, 4); }
+int fw_header(lzf_frame_writer* w) {
+    if (w->header_done) return LZF_OK;
+    uint8_t h[32];
+    const size_t n = write_header(&w->s, w->bd, h);
+    w->header_done = true;
+    return fw_put(w, h, n);                                                     // :200 writer.write_all(&header)
+}
+// length word, payload, optional checksum of one block (:244-263)
+int fw_emit_block(lzf_frame_writer* w, const uint8_t* payload, uint32_t n, bool stored, uint32_t sum) {
+    int rc = fw_put32(w, stored ? (n | INCOMPRESSIBLE) : n);
+    if (rc == LZF_OK) rc = fw_put(w, payload, n);
+    if (rc == LZF_OK && w->s.block_checksums) rc = fw_put32(w, sum);
+    return rc;
+}
+// block checksums of a batch on the device (one launch), like the other drivers
+int fw_sums(const std::vector<const uint8_t*>& p, const std::vector<uint64_t>& n, std::vector<uint32_t>& out) {
+    out.assign(p.size(), 0);
+    if (p.empty()) return LZF_OK;
+    g_reader_device_hashes += p.size();
+    return lzf_xxh32_batch_host(p.data(), n.data(), out.data(), (uint32_t)p.size());
+}
+// independent blocks: the first `nblk` blocks of pending (the last may be short) in one launch
+int fw_flush_independent(lzf_frame_writer* w, size_t nblk, size_t bytes) {
+    const size_t dl = w->dict.size();
+    std::vector<lzf_compress_job> jobs(nblk);
+    std::vector<lzf_job_result> res(nblk);
+    std::vector<uint8_t> inbuf, outbuf(bytes);
+    if (dl) inbuf.resize(nblk * dl + bytes);
+    size_t off = 0, ioff = 0;
+    for (size_t i = 0; i < nblk; ++i) {
+        const size_t n = bytes - off < w->bs ? bytes - off : w->bs;
+        lzf_compress_job& j = jobs[i];
+        memset(&j, 0, sizeof j);
+        if (dl) {                                                               // in_buffer = dictionary ++ block (:218-222,:268)
+            memcpy(inbuf.data() + ioff, w->dict.data(), dl);
+            memcpy(inbuf.data() + ioff + dl, w->pending.data() + off, n);
+            j.input = inbuf.data() + ioff; j.input_len = dl + n; j.cursor = dl; ioff += dl + n;
+            if (w->seeded) { j.table = &w->templ; j.flags = LZF_CJOB_TABLE_READONLY; }      // table = template_table.clone() (:220,:270)
+        } else { j.input = w->pending.data() + off; j.input_len = n; j.cursor = 0; }
+        j.out = outbuf.data() + off; j.out_cap = n;                             // NoPartialWrites(&mut out_buffer[..read_bytes]) (:242)
+        j.table_kind = LZF_TABLE_U32;
+        off += n;
+    }
+    int rc = lzf_compress_batch_host(jobs.data(), res.data(), (uint32_t)nblk);
+    if (rc != LZF_OK) return rc;
+    std::vector<const uint8_t*> pp(nblk); std::vector<uint64_t> pn(nblk); std::vector<uint32_t> sums;
+    off = 0;
+    for (size_t i = 0; i < nblk; ++i) {
+        const size_t n = bytes - off < w->bs ? bytes - off : w->bs;
+        if (res[i].status != LZF_OK && res[i].status != LZF_OUTPUT_FULL) return res[i].status;
+        const bool stored = res[i].status == LZF_OUTPUT_FULL;                  // :250-255
+        pp[i] = stored ? w->pending.data() + off : outbuf.data() + off;
+        pn[i] = stored ? n : res[i].out_len;
+        off += n;
+    }
+    if (w->s.block_checksums) { rc = fw_sums(pp, pn, sums); if (rc != LZF_OK) return rc; }
+    off = 0;
+    for (size_t i = 0; i < nblk; ++i) {
+        const size_t n = bytes - off < w->bs ? bytes - off : w->bs;
+        if (w->s.content_checksum) w->content.update(w->pending.data() + off, n);          // :233-235
+        rc = fw_emit_block(w, pp[i], (uint32_t)pn[i], res[i].status == LZF_OUTPUT_FULL, w->s.block_checksums ? sums[i] : 0);
+        if (rc != LZF_OK) return rc;
+        off += n;
+    }
+    w->pending.erase(w->pending.begin(), w->pending.begin() + (ptrdiff_t)bytes);
+    return LZF_OK;
+}
+// linked blocks: one block (n bytes of pending) behind the carried window, the table carried (:221-275)
+int fw_flush_linked(lzf_frame_writer* w, size_t n) {
+    const size_t window_offset = w->in_buffer.size();
+    w->in_buffer.insert(w->in_buffer.end(), w->pending.begin(), w->pending.begin() + (ptrdiff_t)n);
+    if (w->s.content_checksum) w->content.update(w->in_buffer.data() + window_offset, n);
+    std::vector<uint8_t> outbuf(n);
+    lzf_compress_job j; memset(&j, 0, sizeof j);
+    j.input = w->in_buffer.data(); j.input_len = w->in_buffer.size(); j.cursor = window_offset;
+    j.out = outbuf.data(); j.out_cap = n; j.table = &w->table; j.table_kind = LZF_TABLE_U32;
+    lzf_job_result r{};
+    int rc = lzf_compress_batch_host(&j, &r, 1);
+    if (rc != LZF_OK) return rc;
+    if (r.status != LZF_OK && r.status != LZF_OUTPUT_FULL) return r.status;
+    const bool stored = r.status == LZF_OUTPUT_FULL;
+    const uint8_t* payload = stored ? w->in_buffer.data() + window_offset : outbuf.data();
+    const uint32_t plen = stored ? (uint32_t)n : (uint32_t)r.out_len;
+    uint32_t sum = 0;
+    if (w->s.block_checksums) { std::vector<const uint8_t*> pp{payload}; std::vector<uint64_t> pn{plen}; std::vector<uint32_t> so; rc = fw_sums(pp, pn, so); if (rc != LZF_OK) return rc; sum = so[0]; }
+    rc = fw_emit_block(w, payload, plen, stored, sum);
+    if (rc != LZF_OK) return rc;
+    if (w->in_buffer.size() > LZF_WINDOW_SIZE) {                                // :271-275
+        const size_t forget = w->in_buffer.size() - LZF_WINDOW_SIZE;
+        w->table.offset += forget;
+        w->in_buffer.erase(w->in_buffer.begin(), w->in_buffer.begin() + (ptrdiff_t)forget);
+    }
+    w->pending.erase(w->pending.begin(), w->pending.begin() + (ptrdiff_t)n);
+    return LZF_OK;
+}
+// compress what is buffered: whole blocks only, or (final) everything
+int fw_drain(lzf_frame_writer* w, bool final) {
+    for (;;) {
+        const size_t have = w->pending.size();
+        if (have == 0) return LZF_OK;
+        int rc;
+        if (w->s.independent_blocks) {
+            size_t nfull = have / w->bs;
+            if (!final && nfull < w->per_launch) return LZF_OK;
+            size_t nblk = nfull < w->per_launch ? nfull : w->per_launch, bytes = nblk * w->bs;
+            if (final && nblk < w->per_launch && have > bytes) { ++nblk; bytes = have; }    // the short last block rides along
+            if (nblk == 0) return LZF_OK;
+            rc = fw_flush_independent(w, nblk, bytes);
+        } else {
+            if (!final && have < w->bs) return LZF_OK;
+            rc = fw_flush_linked(w, have < w->bs ? have : w->bs);
+        }
+        if (rc != LZF_OK) { w->dead = true; return rc; }
+    }
+}
+}  // namespace
+
+int lzf_frame_writer_new(const lzf_settings* s, lzf_write_all_fn write_all, void* ctx, uint32_t blocks_per_launch, lzf_frame_writer** out) {
+    if (!s || !write_all || !out) return LZF_E_INVALID;
+    *out = nullptr;
+    uint8_t bd;
+    int rc = bd_new(s->block_size, &bd);                                         // :183
+    if (rc != LZF_OK) return rc;
+    lzf_frame_writer* w = new lzf_frame_writer();
+    w->s = *s; w->bd = bd; w->sink = write_all; w->ctx = ctx; w->bs = (size_t)s->block_size;
+    w->per_launch = blocks_per_launch ? blocks_per_launch : 64u;
+    if (s->dictionary && s->dictionary_len) {
+        w->dict.assign(s->dictionary, s->dictionary + s->dictionary_len);
+        rc = seeded_template(w->dict.data(), w->dict.size(), &w->templ);         // :202-214
+        if (rc != LZF_OK) { delete w; return rc; }
+        w->seeded = w->dict.size() >= 8;
+    }
+    w->s.dictionary = w->dict.empty() ? nullptr : w->dict.data();
+    w->table = w->templ;                                                         // :220
+    w->in_buffer = w->dict;                                                      // :218 in_buffer.extend_from_slice(block_initializer)
+    *out = w;
+    return LZF_OK;
+}
+
+int lzf_frame_writer_write(lzf_frame_writer* w, const uint8_t* data, size_t len) {
+    if (!w || (!data && len)) return LZF_E_INVALID;
+    if (w->dead || w->finished) return w->dead && w->sink_err ? LZF_OUTPUT_FULL : LZF_E_INVALID;
+    int rc = fw_header(w);
+    if (rc != LZF_OK) return rc;
+    // (whole launches' worth is compressed as soon as it is there, so `pending` never holds more than one launch + one feed)
+    size_t done = 0;
+    while (done < len) {
+        const size_t room = w->s.independent_blocks ? (size_t)w->per_launch * w->bs : w->bs;
+        size_t take = len - done;
+        if (w->pending.size() < room && take > room - w->pending.size()) take = room - w->pending.size();
+        w->pending.insert(w->pending.end(), data + done, data + done + take);
+        done += take;
+        rc = fw_drain(w, false);
+        if (rc != LZF_OK) return rc;
+    }
+    return LZF_OK;
+}
+
+int lzf_frame_writer_finish(lzf_frame_writer* w) {
+    if (!w) return LZF_E_INVALID;
+    if (w->dead || w->finished) return w->dead && w->sink_err ? LZF_OUTPUT_FULL : LZF_E_INVALID;
+    int rc = fw_header(w);
+    if (rc == LZF_OK) rc = fw_drain(w, true);
+    if (rc == LZF_OK) rc = fw_put32(w, 0);                                       // :277 EndMark
+    if (rc == LZF_OK && w->s.content_checksum) rc = fw_put32(w, w->content.digest());      // :279-281
+    w->finished = true;
+    return rc;
+}
+
+int lzf_frame_writer_sink_error(const lzf_frame_writer* w) { return w ? w->sink_err : 0; }
+void lzf_frame_writer_free(lzf_frame_writer* w) { delete w; }
+
 }  // extern "C"

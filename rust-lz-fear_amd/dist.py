@@ -96,17 +96,22 @@ def frame_header(content_checksum=False, block_size=4 << 20, independent=True, b
     return bytes([0x04, 0x22, 0x4D, 0x18]) + desc + bytes([hc])
 
 
-def gather_frame_device(d_cres, comp, src, block_size, n_local, n_blocks, frame, dist_mod, rank, world, device_mod, header):
+def gather_frame_device(d_cres, comp, src, block_size, n_local, n_blocks, frame, dist_mod, rank, world, device_mod, header, raw_lens=None):
     """Pack this rank's compressed (or stored) blocks into `frame` (uint8 CUDA tensor) at their final offsets, exchange the
     segments, write header and EndMark.  d_cres: the lzf_job_result array of the rank's compress launch (HBM); comp: the
-    compressed slots (stride block_size); src: the rank's raw blocks.  Returns (frame bytes, total compressed payload bytes)."""
+    compressed slots (stride block_size); src: the rank's raw blocks; raw_lens: int64 CUDA tensor of the blocks' raw lengths
+    (None: every block is block_size long — only the stream's last block may be shorter).
+    Returns (frame bytes, total compressed payload bytes)."""
     dev = frame.device
     res = d_cres.view(torch.int64).view(-1, 2)[:n_local]
     out_len = res[:, 0]
     status = res[:, 1] & 0xFFFFFFFF
     okm = status == ffi.OK                                        # else OutputFull: stored raw (framed/compress.rs:250-255)
-    plen = torch.where(okm, out_len, torch.full_like(out_len, block_size))
-    word = torch.where(okm, out_len, torch.full_like(out_len, block_size | 0x80000000))
+    if not bool(torch.all(okm | (status == ffi.OUTPUT_FULL))):   # anything else is not "store it raw" (compress.rs:250-255 asserts the kind)
+        raise RuntimeError(f"compress statuses {torch.unique(status).tolist()}: only OK / OUTPUT_FULL can be framed")
+    rawl = torch.full_like(out_len, block_size) if raw_lens is None else raw_lens.to(torch.int64)
+    plen = torch.where(okm, out_len, rawl)
+    word = torch.where(okm, out_len, rawl | 0x80000000)
     max_blocks = (n_blocks + world - 1) // world
     tab = torch.zeros(max_blocks, dtype=torch.int64, device=dev)
     tab[:n_local] = plen

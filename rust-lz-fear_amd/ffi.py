@@ -67,7 +67,7 @@ class FrameInfo(C.Structure):
 
 EXPORTS = [
     "lzf_abi_version", "lzf_last_error", "lzf_device_count", "lzf_compress_batch",
-    "lzf_decompress_batch", "lzf_table_seed_from_dictionary", "lzf_table_offset", "lzf_table_offset_batch",
+    "lzf_decompress_batch", "lzf_last_decompress_launch", "lzf_table_replace_host", "lzf_table_offset_host", "lzf_compress2_host_writer", "lzf_table_seed_from_dictionary", "lzf_table_offset", "lzf_table_offset_batch",
     "lzf_chain_decompress_step",
     "lzf_xxh32_batch", "lzf_copy_ranges", "lzf_compress_batch_host", "lzf_decompress_batch_host", "lzf_xxh32_batch_host",
 ]
@@ -77,6 +77,7 @@ FRAME_EXPORTS = [
     "lzf_xxh32_reset", "lzf_xxh32_update", "lzf_xxh32_digest",
     "lzf_frame_reader_new", "lzf_frame_reader_free", "lzf_frame_reader_info", "lzf_frame_reader_decode_block",
     "lzf_frame_reader_finished", "lzf_frame_reader_consumed",
+    "lzf_frame_writer_new", "lzf_frame_writer_write", "lzf_frame_writer_finish", "lzf_frame_writer_sink_error", "lzf_frame_writer_free",
     "lzf_frame_get_stats", "lzf_frame_release_scratch", "lzf_frame_set_host_threads", "lzf_frame_set_memory_budget",
 ]
 
@@ -114,6 +115,7 @@ def lib():
                                       "(hipcc --offload-arch=gfx950); there is no CPU fallback")
         L = C.CDLL(path)
         L.lzf_last_error.restype = C.c_char_p
+        L.lzf_last_decompress_launch.restype = C.c_char_p
         L.lzf_compress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.lzf_decompress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.lzf_table_seed_from_dictionary.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]

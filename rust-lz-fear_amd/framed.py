@@ -25,6 +25,59 @@ class FrameError(Exception):
         self.partial = partial
 
 
+class LZ4FrameWriter:
+    """lzf_frame_writer_*: compress_internal's loop (src/framed/compress.rs:160-282) with the stream fed piece by piece."""
+    _WRITE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
+
+    def __init__(self, settings, sink, content_size=None, blocks_per_launch=0):
+        self._exc = None
+
+        def cb(ctx, p, n):
+            try:
+                sink(bytes(p[:n]))
+                return 0
+            except Exception as e:              # the sink refuses: the writer stops (io::Error of the reference's writer)
+                self._exc = e
+                return 1
+        self._cb = self._WRITE(cb)
+        self._s = settings._struct(content_size)
+        self._w = C.c_void_p()
+        L = ffi.lib()
+        L.lzf_frame_writer_new.argtypes = [C.c_void_p, self._WRITE, C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p)]
+        L.lzf_frame_writer_write.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.lzf_frame_writer_finish.argtypes = [C.c_void_p]
+        L.lzf_frame_writer_free.argtypes = [C.c_void_p]
+        rc = L.lzf_frame_writer_new(C.byref(self._s), self._cb, None, blocks_per_launch, C.byref(self._w))
+        if rc != 0:
+            ffi.check(rc)
+            raise FrameError(rc)
+
+    def _done(self, rc):
+        if rc == ffi.OUTPUT_FULL and self._exc is not None:
+            raise self._exc
+        if rc != 0:
+            ffi.check(rc)
+            raise FrameError(rc)
+
+    def write(self, data):
+        data = bytes(data)
+        self._done(ffi.lib().lzf_frame_writer_write(self._w, data, len(data)))
+
+    def finish(self):
+        self._done(ffi.lib().lzf_frame_writer_finish(self._w))
+
+    def close(self):
+        if self._w:
+            ffi.lib().lzf_frame_writer_free(self._w)
+            self._w = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class CompressionSettings:
     """src/framed/compress.rs:36-55; the setters return self like the reference's builder."""
 
@@ -89,6 +142,12 @@ class CompressionSettings:
 
     def compress(self, data):                    # :137-140
         return self._run(data, None)
+
+    def writer(self, sink, content_size=None, blocks_per_launch=0):
+        """Streaming form of compress / compress_with_size_unchecked (:138-146): feed the stream with .write(bytes) in any
+        granularity, call .finish(); the frame's bytes go to `sink(bytes)` (raise to refuse) piece by piece, in the
+        reference's order (lzf_frame_writer_* of lzfear_frame.h).  Byte-identical to compress() of the whole stream."""
+        return LZ4FrameWriter(self, sink, content_size, blocks_per_launch)
 
     def compress_many(self, datas):
         """`compress` of every buffer in `datas`, all frames through the same launches (lzf_frame_compress_many): the

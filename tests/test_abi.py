@@ -33,7 +33,7 @@ def test_header_declares_expected_entry_points():
 def test_library_exports_every_declared_symbol(lib):
     for name in declared_functions() + declared_functions("lzfear_frame.h"):
         assert hasattr(lib, name), name
-    assert lib.lzf_abi_version() == 1
+    assert lib.lzf_abi_version() == 2
     assert sorted(declared_functions("lzfear_frame.h")) == sorted(ffi.FRAME_EXPORTS)
 
 
@@ -60,6 +60,46 @@ def test_frame_layer_host_only_pieces(lib):
     assert info.block_maxsize == 4 << 20 and info.header_len == 7
     assert lib.lzf_frame_read_header(b"\x00" * 7, 7, C.byref(info)) == 17          # WrongMagic
     assert lib.lzf_frame_read_header(frame[:5], 5, C.byref(info)) == 16             # InputError
+
+
+def test_table_replace_host_is_encoder_table_replace(lib):
+    """lzf_table_replace_host / lzf_table_offset_host = EncoderTable::replace / ::offset (src/raw/compress/mod.rs:64-74, :88-99)
+    on the C ABI's host tables: the same return values and the same table as the oracle's restatement, over a table whose
+    offset is carried forward like a linked-block stream's (framed/compress.rs:271-275), the < 8-byte tail rule of
+    hash_for_u32 (:43) and the contract violations (:67, :92).  Pure host code: no GPU needed."""
+    import ctypes as C
+    import numpy as np
+    import oracle_ffi as o
+    L = o.lib()
+    L.lzfo_u32_replace.restype = C.c_size_t; L.lzfo_u16_replace.restype = C.c_size_t
+    L.lzfo_u32_replace.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int)]
+    L.lzfo_u16_replace.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int)]
+    lib.lzf_table_replace_host.argtypes = [C.c_void_p, C.c_uint32, C.c_char_p, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]
+    lib.lzf_table_offset_host.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64]
+    rng = np.random.default_rng(3)
+    data = bytes(rng.integers(0, 7, 70000, dtype=np.uint8))              # few symbols: slots collide and repeat
+    for kind, ours, ref, fn in ((ffi.TABLE_U32, ffi.U32Table(), o.U32Table(), L.lzfo_u32_replace), (ffi.TABLE_U16, ffi.U16Table(), o.U16Table(), L.lzfo_u16_replace)):
+        n = len(data) if kind == ffi.TABLE_U32 else 30000
+        for rnd in range(3):
+            for pos in list(rng.integers(0, n - 8, 3000)) + [n - 8, n - 7, n - 5, n - 4]:
+                pos = int(pos)
+                prev = C.c_uint64(0); contract = C.c_int(0)
+                rc = lib.lzf_table_replace_host(C.addressof(ours), kind, data, n, pos, C.byref(prev))
+                exp = fn(C.addressof(ref), data, n, pos, C.byref(contract))
+                assert (rc == ffi.CONTRACT) == bool(contract.value), (kind, pos, rc)
+                if rc == 0:
+                    assert prev.value == exp, (kind, pos)
+            add = 4000 if kind == ffi.TABLE_U32 else 9000
+            assert lib.lzf_table_offset_host(C.addressof(ours), kind, add) == 0
+            ref.offset += add
+            assert bytes(ours) == bytes(ref)
+    t = ffi.U16Table()
+    assert lib.lzf_table_replace_host(C.addressof(t), ffi.TABLE_U16, data, 100, 98, None) == ffi.CONTRACT      # fewer than 4 bytes (:59)
+    t.offset = 65000
+    assert lib.lzf_table_replace_host(C.addressof(t), ffi.TABLE_U16, data, 30000, 600, None) == ffi.CONTRACT   # beyond u16 (:92)
+    t32 = ffi.U32Table(); t32.offset = 0xFFFFFFF0
+    assert lib.lzf_table_replace_host(C.addressof(t32), ffi.TABLE_U32, data, 30000, 600, None) == ffi.CONTRACT  # beyond u32 (:67)
+    assert lib.lzf_table_replace_host(C.addressof(t32), ffi.TABLE_U32, data, 100, 101, None) == ffi.CONTRACT
 
 
 def test_struct_layouts_match_header():

@@ -49,6 +49,57 @@ def test_flag_matrix_exact_frame_bytes(bits):
     assert framed.decompress_frame(got, dictionary=kw.get("dictionary", b"")) == data
 
 
+@pytest.mark.parametrize("bits", range(32))
+def test_streaming_writer_flag_matrix_exact_frame_bytes(bits):
+    """lzf_frame_writer_* (the streaming form of CompressionSettings::compress, compress.rs:138-157,:221-276): the same flag
+    matrix, the stream fed in three granularities (7 bytes to whole blocks and more), launches of 1, 3 and 64 blocks — every
+    time the oracle's frame, byte for byte, and the one-call lzf_frame_compress's."""
+    data = synth.silesia_mix(0, 700_000).tobytes()
+    kw = dict(content_checksum=not (bits & 1), independent_blocks=not (bits & 2),
+              block_size=(256 << 10) if bits & 4 else (64 << 10), block_checksums=bool(bits & 1))
+    if bits & 8:
+        kw["dictionary"] = bytes([1, 3, 3, 7]) if bits & 4 else synth.silesia_mix(900_000, 930_000).tobytes(); kw["dictionary_id"] = None
+    g, okw = settings_pair(**kw)
+    size = len(data) if bits & 16 else None
+    rc, want = o.frame_compress(data, o.make_settings(content_size=size, **okw))
+    assert rc == 0
+    assert (g.compress_with_size(data) if size is not None else g.compress(data)) == want
+    rng = np.random.default_rng(bits)
+    for per_launch, feed in ((1, "tiny"), (3, "ragged"), (0, "big")):
+        got = bytearray()
+        w = g.writer(got.extend, content_size=size, blocks_per_launch=per_launch)
+        pos = 0
+        while pos < len(data):
+            n = 7 if (feed == "tiny" and pos < 300) else int(rng.integers(1, 90_000)) if feed != "big" else 300_001
+            w.write(data[pos:pos + n]); pos += n
+        w.finish(); w.close()
+        assert bytes(got) == want, (bits, feed)
+    # the empty stream: header, EndMark, checksum
+    got = bytearray(); w = g.writer(got.extend, content_size=0 if size is not None else None); w.finish(); w.close()
+    assert bytes(got) == o.frame_compress(b"", o.make_settings(content_size=0 if size is not None else None, **okw))[1]
+
+
+def test_streaming_writer_refusing_sink_stops_the_writer():
+    """A sink that refuses (raises) after some bytes: the write that crosses it reports the sink's error, what was accepted
+    is a prefix of the frame, and the writer is dead."""
+    data = synth.silesia_mix(0, 300_000).tobytes()
+    g, okw = settings_pair(block_size=64 << 10)
+    want = o.frame_compress(data, o.make_settings(**okw))[1]
+    for budget in (0, 5, 7, 11, 40_000, len(want) - 3):
+        got = bytearray()
+        def sink(b):
+            if len(got) + len(b) > budget:
+                raise IOError("full")
+            got.extend(b)
+        w = g.writer(sink, blocks_per_launch=2)
+        with pytest.raises(IOError):
+            w.write(data); w.finish()
+        assert want.startswith(bytes(got)) and len(got) <= budget
+        with pytest.raises(Exception):
+            w.write(b"x")
+        w.close()
+
+
 def test_default_settings_4mib_blocks():
     data = synth.silesia_mix(5 << 20, 15 << 20).tobytes()          # 2.5 blocks of 4 MiB
     got = framed.CompressionSettings().compress(data)
@@ -305,6 +356,45 @@ def test_config4_sharded_frame_over_rccl():
         frame = lzdist.assemble_frame(st, allp, allc, raw_len, ffi.lib().lzf_xxh32(raw, len(raw), 0))
         assert frame == o.frame_compress(raw, o.make_settings(block_size=BS))[1]
         assert framed.decompress_frame(frame) == raw
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_frame_device_nccl_world1():
+    """The function `bench.py --workload config4` times (dist.gather_frame_device: size-table all-gather, in-place packing
+    with lzf_copy_ranges, exact-size P2P segments) on the nccl backend at world size 1: the WHOLE frame equals the oracle's
+    frame — a stored (incompressible) block and a short last block included — and decodes back.  (World size 2: gloo,
+    tests/test_dist_gloo.py.)"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from rust_lz_fear_amd import device, ffi, dist as lzdist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        BS = 4 << 20
+        data = np.concatenate([synth.log_text(0, 2 * BS), np.frombuffer(vectors.rng_bytes(5, BS), np.uint8),
+                               synth.log_text(2 * BS, 3 * BS + 777_777)])
+        d_in = torch.from_numpy(data).cuda()
+        blocks = device.BlockSet(d_in, BS); n = blocks.n
+        assert n == 5 and int(blocks.lens[-1]) == 777_777
+        d_out = torch.empty(n * BS, dtype=torch.uint8, device="cuda")
+        d_res = torch.zeros(n * 16, dtype=torch.uint8, device="cuda")
+        device.compress_batch(device.to_device(blocks.compress_jobs(d_out, BS), "cuda"), d_res, n)
+        torch.cuda.synchronize()
+        res = device.results_to_host(d_res, n)
+        assert ffi.OUTPUT_FULL in set(int(x) for x in res["status"])          # the random block is stored
+        frame = torch.zeros(64 + n * (BS + 8), dtype=torch.uint8, device="cuda")
+        header = lzdist.frame_header(content_checksum=False, block_size=BS)
+        raw_lens = torch.from_numpy(blocks.lens.astype(np.int64)).cuda()
+        flen, ctot = lzdist.gather_frame_device(d_res, d_out, d_in, BS, n, n, frame, dist, 0, 1, device, header, raw_lens=raw_lens)
+        torch.cuda.synchronize()
+        mine = frame[:flen].cpu().numpy().tobytes()
+        raw = data.tobytes()
+        rc, ref = o.frame_compress(raw, o.make_settings(block_size=BS, content_checksum=False))
+        assert rc == 0 and mine == ref
+        assert framed.decompress_frame(mine) == raw
     finally:
         dist.destroy_process_group()
 

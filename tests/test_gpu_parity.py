@@ -312,6 +312,47 @@ def test_oversized_but_ok_literals_and_out_capacity():
         assert rc == erc and (rc != 0 or out == eout)
 
 
+def test_compress2_for_any_writer_replays_the_reference_write_calls():
+    """lzf_compress2_host_writer = compress2<W: Write, T>(input, cursor, table, writer) (mod.rs:165-166) without a capacity
+    argument: the device compresses against the worst-case bound, then the reference's write calls are replayed into the
+    writer (token, length tail 4 + 1 bytes at a time, literals, offset, length tail: mod.rs:150-163, :243-260).  A sink that
+    refuses the first call that does not fit a budget (NoPartialWrites, framed/compress.rs:294-314) — at EVERY budget from 0
+    to the stream's length: the accepted bytes, the status and the table afterwards equal the oracle's compress2 into the
+    same sink; the refusing writer's error code comes back."""
+    import ctypes as C
+    L = ffi.lib()
+    WRITE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_uint8), C.c_size_t)
+    L.lzf_compress2_host_writer.argtypes = [C.c_char_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint32, WRITE, C.c_void_p, C.POINTER(C.c_int)]
+    text = synth.gen_text_zipf(4, 900).tobytes()
+    data = text[:300] + bytes(40) + text[100:420] + bytes([7]) * 700 + text[:64]     # literals, zero runs, a 700-byte match (length tail of 3 bytes)
+    for kind in (ffi.TABLE_U32, ffi.TABLE_U16):
+        for cursor in (0, 100):
+            full = o.compress2(data, cursor=cursor, kind=kind)[1]
+            assert 20 < len(full) < 600
+            for budget in list(range(0, len(full) + 2)):
+                got = bytearray(); calls = []
+                def sink(ctx, p, n):
+                    calls.append(n)
+                    if len(got) + n > budget:
+                        return 42
+                    got.extend(bytes(p[:n]))
+                    return 0
+                t = ffi.U32Table() if kind == ffi.TABLE_U32 else ffi.U16Table()
+                te = o.new_table(kind)
+                werr = C.c_int(0)
+                rc = L.lzf_compress2_host_writer(data, len(data), cursor, C.addressof(t), kind, WRITE(sink), None, C.byref(werr))
+                erc, eout = o.compress2(data, cursor=cursor, kind=kind, table=te, cap=budget)
+                assert rc == erc, (kind, cursor, budget, rc, erc)
+                assert bytes(got) == eout, (kind, cursor, budget)
+                assert bytes(t) == bytes(te), (kind, cursor, budget)
+                assert werr.value == (42 if rc == ffi.OUTPUT_FULL else 0)
+                assert all(n in (1, 2, 4) or n > 0 for n in calls)
+    # the empty payload writes nothing (mod.rs:171), a NULL table is T::default()
+    calls = []
+    rc = L.lzf_compress2_host_writer(data, len(data), len(data), None, ffi.TABLE_U32, WRITE(lambda c, p, n: calls.append(n) or 0), None, None)
+    assert rc == 0 and calls == []
+
+
 def test_compress_cursor_past_the_end_is_ok_and_empty():
     """compress2 with cursor >= input.len(): the loop at mod.rs:171 never runs -> Ok(()), nothing written, table untouched."""
     data = synth.text_zipf_64k().tobytes()[:5000]
