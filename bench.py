@@ -150,7 +150,9 @@ def cpu_baseline(raw_blocks, comp_blocks, budget_s):
 def traffic_for(kernel_name, which, n_jobs):
     """FETCH_SIZE (x2: gfx950 correction) + WRITE_SIZE of the launched kernel, from the separate --pmc passes committed as
     profiles/r02_hbm_traffic.json (tools/refresh_profiles.sh), scaled by job count; None when the profile is of another kernel."""
-    path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
+    if not os.path.exists(path):
+        path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
     if not os.path.exists(path):
         return None
     tj = json.load(open(path)).get(which)

@@ -117,7 +117,8 @@ uint8_t* Staging::pinned(size_t bytes) {
     if (device_ != dev) { release(); device_ = dev; }
     if (bytes <= pin_cap_ && pin_) return pin_;
     if (pin_) { (void)hipHostFree(pin_); pin_ = nullptr; pin_cap_ = 0; }
-    const size_t cap = round_up(bytes ? bytes : 1, 64u << 20);
+    // (small calls pin little: 1 MiB steps below 16 MiB, 64 MiB steps beyond)
+    const size_t cap = round_up(bytes ? bytes : 1, bytes < (16u << 20) ? (1u << 20) : (64u << 20));
     void* p = nullptr;
     if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
     pin_ = static_cast<uint8_t*>(p); pin_cap_ = cap;

@@ -1,21 +1,21 @@
 #!/bin/bash
 # Regenerates the round's measurement artifacts on the GPU box (run through gpurun from the repo root), product library only:
-#   gpurun_out/r02/bench_default.json          python bench.py (the driver's default invocation)
-#   gpurun_out/r02/kernel_stats.txt            rocprofv3 --kernel-trace --stats of the same command
-#   gpurun_out/r02/pmc_{FETCH,WRITE}_SIZE.txt  separate --pmc passes at 48 copies (1 step; 2352 compressed blocks: the same kernels
+#   gpurun_out/r03/bench_default.json          python bench.py (the driver's default invocation)
+#   gpurun_out/r03/kernel_stats.txt            rocprofv3 --kernel-trace --stats of the same command
+#   gpurun_out/r03/pmc_{FETCH,WRITE}_SIZE.txt  separate --pmc passes at 48 copies (1 step; 2352 compressed blocks: the same kernels
 #                                               as the default run — counter collection at 240 copies does not finish) for HBM traffic
-#   gpurun_out/r02/hbm_traffic.json            the two passes as the file bench.py reads (copy to profiles/r02_hbm_traffic.json)
-#   gpurun_out/r02/bench_config4.json          python bench.py --workload config4
-#   gpurun_out/r02/bench_240x48.json, bench_240x1.json   seed-sensitivity check at full size: 240 copies from 48 seeds / from 1 seed
+#   gpurun_out/r03/hbm_traffic.json            the two passes as the file bench.py reads (copy to profiles/r03_hbm_traffic.json)
+#   gpurun_out/r03/bench_config4.json          python bench.py --workload config4
+#   gpurun_out/r03/bench_240x48.json, bench_240x1.json   seed-sensitivity check at full size: 240 copies from 48 seeds / from 1 seed
 set -u
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02; rm -rf $O; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; rm -rf $O; mkdir -p $O
 cd $R && timeout 1500 python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log > $O/bench_default.json
 cd /tmp; export TMPDIR=/tmp
-(cd $R && timeout 1500 rocprofv3 --kernel-trace --stats -d $O/prof -o x -- python bench.py --no-cpu --no-e2e > $O/prof.log 2>&1)
+(cd $R && timeout 1500 rocprofv3 --kernel-trace --stats -d $O/prof -o x -- python bench.py --no-cpu --no-e2e --no-config4 > $O/prof.log 2>&1)
 DB=$(ls $O/prof/*/x_results.db $O/prof/x_results.db 2>/dev/null | head -1)
 [ -n "$DB" ] && python $R/profiles/summarize_rocpd.py $DB > $O/kernel_stats.txt
 for c in FETCH_SIZE WRITE_SIZE; do
-  (cd $R && timeout 420 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python bench.py --copies 48 --distinct 1 --steps 1 --warmup 0 --no-cpu --no-e2e --no-verify > $O/pmc_$c.log 2>&1)
+  (cd $R && timeout 420 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python bench.py --copies 48 --distinct 1 --steps 1 --warmup 0 --no-cpu --no-e2e --no-verify --no-config4 > $O/pmc_$c.log 2>&1)
   rm -rf $O/pmc_$c/*/*.db
   f=$(ls $O/pmc_$c/*/*_counter_collection.csv 2>/dev/null | head -1)
   [ -n "$f" ] && python - "$f" "$c" > $O/pmc_$c.txt <<'PY'
@@ -39,9 +39,9 @@ def per_dispatch(counter, needle):
             best = (p[1], float(p[5].split()[-1]), p[3].split()[-1])
     return best
 out = {"_what": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace) of `python bench.py --copies 48 --distinct 1 --steps 1 --warmup 0 --no-cpu --no-e2e --no-verify` "
-                "(48 copies: the same kernels as the default 240-copy run; bench.py scales by job count) on MI355X, round 2; per dispatch, in the counters' KB units (x1024 bytes). "
+                "(48 copies: the same kernels as the default 240-copy run; bench.py scales by job count) on MI355X, round 3; per dispatch, in the counters' KB units (x1024 bytes). "
                 "gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half of the bytes of wide streaming reads; bench.py uses 2 x FETCH + WRITE as the upper bound."}
-dk = line["roofline"]["kernel"].split("<")[0]
+dk = line["roofline"]["kernel"].replace(",", ", ")        # the launched variant exactly, as rocprofv3 prints it (the batch sweep launches others)
 for which, needle, jobs in (("decompress", dk, line["kernel_only"]["blocks_per_gpu"]), ("compress", "lzf_compress_compact_kernel<false>", line["config"]["blocks_per_gpu"])):
     f, w = per_dispatch("FETCH_SIZE", needle), per_dispatch("WRITE_SIZE", needle)
     if f and w:
@@ -51,8 +51,7 @@ json.dump(out, open(os.path.join(O, "hbm_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
 PY
 cd $R && timeout 900 python bench.py --workload config4 > $O/bench_config4.log 2>&1; tail -1 $O/bench_config4.log > $O/bench_config4.json
-# seed sensitivity at full size: 48 seeds and 1 seed against the default 12 (240 seeds: `--distinct 240`, three minutes of generation,
-# run once by hand: profiles/r02_bench_240x240distinct.json)
-cd $R && timeout 900 python bench.py --copies 240 --distinct 48 --no-cpu --no-e2e > $O/bench_240x48.log 2>&1; tail -1 $O/bench_240x48.log > $O/bench_240x48.json
-cd $R && timeout 900 python bench.py --copies 240 --distinct 1 --no-cpu --no-e2e > $O/bench_240x1.log 2>&1; tail -1 $O/bench_240x1.log > $O/bench_240x1.json
-cut -c1-900 $O/bench_default.json; head -12 $O/kernel_stats.txt; cat $O/pmc_FETCH_SIZE.txt $O/pmc_WRITE_SIZE.txt; cut -c1-400 $O/bench_config4.json; cut -c1-300 $O/bench_240x48.json; cut -c1-300 $O/bench_240x1.json
+# the segmented pipeline, kernel by kernel, at 1 / 4 / 8 / 15 copies of the corpus (49 ... 735 blocks), and the pair kernel on the same batches
+bash $R/tools/gpu_seg_stats.sh 1 4 8 15 > $O/seg_kernel_stats.txt 2>&1
+VARIANT=noseg bash $R/tools/gpu_seg_stats.sh 1 4 8 15 > $O/noseg_kernel_stats.txt 2>&1
+cut -c1-1500 $O/bench_default.json; head -14 $O/kernel_stats.txt; cat $O/pmc_FETCH_SIZE.txt $O/pmc_WRITE_SIZE.txt; cut -c1-600 $O/bench_config4.json; cat $O/seg_kernel_stats.txt; grep "==\|jobs\|paired" $O/noseg_kernel_stats.txt
