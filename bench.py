@@ -166,6 +166,14 @@ def last_decompress_launch(ffi):
     return ffi.lib().lzf_last_decompress_launch().decode()
 
 
+def issue_ceiling(copies, kernel_ms, achieved_gbs, cus=256):
+    ipseq, seq_per_copy, best_rate = 27.96, 11.71e6, 3.29            # wave-instructions per sequence; sequences per copy; instr / ns / CU (32 waves per CU)
+    rate = ipseq * seq_per_copy * copies / (kernel_ms * 1e-3) / 1e9 / cus
+    ceil_gbs = achieved_gbs * best_rate / rate
+    return {"wave_instructions_per_sequence": ipseq, "retired_per_ns_per_cu": round(rate, 3), "best_measured_mix_per_ns_per_cu": best_rate,
+            "ceiling_gbs": round(ceil_gbs, 1), "ceiling_frac_of_hbm": round(ceil_gbs / HBM_PEAK_GBS, 4), "achieved_frac_of_ceiling": round(rate / best_rate, 3)}
+
+
 def timed_launches(torch, fn, steps):
     """Run fn() `steps` times; HIP events on the launch stream bracket each call."""
     evs = []
@@ -440,7 +448,11 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
                      "achieved": round(d_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(d_achieved / HBM_PEAK_GBS, 5), "traffic": d_traffic,
                      "algorithmic_bytes_per_launch": d_bytes, "kernel_ms": round(d_kernel_ms, 4),
-                     "north_star_frac": round(float(lens[kidx].sum()) / (d_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)},
+                     "north_star_frac": round(float(lens[kidx].sum()) / (d_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                     # what one workgroup per block can reach at its instruction count: SQ counters of the launched kernel
+                     # (profiles/r02_decompress_generations.txt: 9.0 SALU + 16.1 VALU + 2.6 LDS + 0.24 VMEM per sequence; 11.71 M sequences
+                     # per corpus copy) against the issue rate a dependent SALU + VALU mix reaches (profiles/r01_issue_mix_microbench.txt)
+                     "issue_ceiling": issue_ceiling(copies, d_kernel_ms, d_achieved)},
         "compress": {"value": round(total_bytes * c_steps / tc_max / 2**30, 3), "unit": "GiB/s (uncompressed bytes compressed per second)",
                      "steps": c_steps, "ms_per_step": round(tc_max / c_steps * 1e3, 3),
                      "roofline": {"bound": "hbm", "kernel": "lzf_compress_compact_kernel<false>",
