@@ -96,13 +96,15 @@ struct SegScratch {
 inline uint32_t seg_nch_host(uint32_t len) { return len <= lzf::kSegChunk ? 1u : 1u + (len - lzf::kSegChunk + lzf::kSegStride - 1u) / lzf::kSegStride; }
 
 // lays the scratch areas of a call out in one stream-ordered allocation; false (and nothing allocated) when the pool has no room
-bool seg_alloc(SegScratch& s, const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n, uint32_t min_in, hipStream_t st) {
+bool seg_alloc(SegScratch& s, const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n, uint32_t min_in, hipStream_t st, uint64_t max_in_hint = ~0ull) {
     lzf::seg_ctx& c = s.ctx;
     c.jobs = d_jobs; c.results = d_results; c.n_jobs = n;
-    c.max_in = kSegMaxIn; c.min_in = min_in;
-    c.maxch = seg_nch_host(kSegMaxIn);
-    c.maxtile = (kSegMaxIn + lzf::kSegTile - 1u) / lzf::kSegTile;
-    c.rec_cap = (uint64_t)n * kSegRecsPerJob;
+    // (a caller that knows an upper bound of its jobs' input sizes gets scratch sized for it: the job array is in HBM, the host cannot look)
+    const uint32_t max_in = max_in_hint < kSegMaxIn ? (uint32_t)(max_in_hint < lzf::kSegChunk ? lzf::kSegChunk : max_in_hint) : kSegMaxIn;
+    c.max_in = max_in; c.min_in = min_in;
+    c.maxch = seg_nch_host(max_in);
+    c.maxtile = (max_in + lzf::kSegTile - 1u) / lzf::kSegTile;
+    { const uint64_t per_job = (uint64_t)max_in / 3u + 192u; c.rec_cap = (uint64_t)n * (per_job < kSegRecsPerJob ? per_job : kSegRecsPerJob); }
     // the ring of a block: 128 KiB holds every distance LZ4 can express (no read-backs from HBM) while a CU has one block,
     // 64 / 32 KiB with read-backs for the oldest few per cent of the sources beyond that
     c.ring_bytes = n <= cu_count() ? 131072u : n <= 2u * cu_count() ? 65536u : 32768u;
@@ -150,10 +152,11 @@ int seg_launch(const lzf::seg_ctx& c, uint32_t upto, hipStream_t st) {
     return LZF_OK;
 }
 // The whole call: pipeline, then the pair kernel over what the pipeline did not finish.
-int seg_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n, uint32_t min_in, hipStream_t st, bool* used) {
+int seg_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n, uint32_t min_in, hipStream_t st, bool* used, uint64_t max_in_hint) {
     SegScratch s;
     *used = false;
-    if (!seg_alloc(s, d_jobs, d_results, n, min_in, st)) return LZF_OK;      // (no scratch: the caller launches the pair kernel over everything)
+    if (max_in_hint < min_in) return LZF_OK;                                      // (no job can be in the pipeline's window)
+    if (!seg_alloc(s, d_jobs, d_results, n, min_in, st, max_in_hint)) return LZF_OK;      // (no scratch: the caller launches the pair kernel over everything)
     *used = true;
     int rc = seg_launch(s.ctx, 8u, st);
     if (rc == LZF_OK) {
@@ -234,6 +237,10 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
 }
 
 int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n_jobs, void* hip_stream) {
+    return lzf_decompress_batch_sized(d_jobs, d_results, n_jobs, ~0ull, hip_stream);
+}
+
+int lzf_decompress_batch_sized(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n_jobs, uint64_t max_input_len, void* hip_stream) {
     if (n_jobs == 0) return LZF_OK;
     if (!d_jobs || !d_results) { g_last_error = "lzf_decompress_batch: NULL job/result array"; return LZF_E_INVALID; }
     int rc = ensure_device();
@@ -273,7 +280,7 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
 #endif
     if (seg_on) {
         bool used = false;
-        rc = seg_decompress(d_jobs, d_results, n_jobs, seg_min_in, st, &used);
+        rc = seg_decompress(d_jobs, d_results, n_jobs, seg_min_in, st, &used, max_input_len);
         if (used) g_last_decompress = n_jobs <= cu_count() ? "segmented: lzf_seg_resolve_pair_kernel<131072> + lzf_decompress_paired_kernel<4096,48,640>"
                                      : n_jobs <= 2u * cu_count() ? "segmented: lzf_seg_resolve_pair_kernel<65536> + lzf_decompress_paired_kernel<4096,48,640>"
                                                                  : "segmented: lzf_seg_resolve_pair_kernel<32768> + lzf_decompress_paired_kernel<4096,48,640>";
@@ -503,7 +510,9 @@ int lzf_decompress_batch_host(const lzf_decompress_job* jobs, lzf_job_result* re
     HIP_TRY(sg.upload(up, in_total, din));
     HIP_TRY(hipMemcpyAsync(djobs, dj.data(), sizeof(lzf_decompress_job) * n_jobs, hipMemcpyHostToDevice, cs));
     HIP_TRY(sg.join_copies(cs));
-    rc = lzf_decompress_batch(djobs, dres, n_jobs, cs);
+    uint64_t max_in = 0;
+    for (uint32_t i = 0; i < n_jobs; ++i) if (jobs[i].input_len > max_in) max_in = jobs[i].input_len;
+    rc = lzf_decompress_batch_sized(djobs, dres, n_jobs, max_in, cs);
     if (rc != LZF_OK) { (void)hipDeviceSynchronize(); return rc; }
     HIP_TRY(hipMemcpyAsync(results, dres, sizeof(lzf_job_result) * n_jobs, hipMemcpyDeviceToHost, cs));
     HIP_TRY(hipStreamSynchronize(cs));

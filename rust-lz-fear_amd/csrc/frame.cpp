@@ -335,7 +335,7 @@ int lzf_frame_reader_decode_block(lzf_frame_reader* r, const uint8_t* dict, size
         j.input = d_in; j.input_len = bl; j.prefix = d_pre; j.prefix_len = prefix_len; j.out = d_out; j.out_cap = cap; j.output_limit = bmax;
         lzf_job_result res; memset(&res, 0, sizeof res);
         HIPR(hipMemcpyAsync(d_meta + 64, &j, sizeof j, hipMemcpyHostToDevice, cs));
-        int rc = lzf_decompress_batch(reinterpret_cast<lzf_decompress_job*>(d_meta + 64), reinterpret_cast<lzf_job_result*>(d_meta + 256), 1, cs);
+        int rc = lzf_decompress_batch_sized(reinterpret_cast<lzf_decompress_job*>(d_meta + 64), reinterpret_cast<lzf_job_result*>(d_meta + 256), 1, bl, cs);
         if (rc != LZF_OK) return rc;
         HIPR(hipMemcpyAsync(&res, d_meta + 256, sizeof res, hipMemcpyDeviceToHost, cs));
         HIPR(hipStreamSynchronize(cs));
@@ -906,7 +906,11 @@ int decompress_group(Staging& sg, std::vector<DFrame>& fr, uint32_t f0, uint32_t
         for (size_t k = 0; k < n_steps; ++k) {
             if (n_chain) RCOK(lzf_chain_decompress_step(d_steps + k * n_chain, d_state, n_chain, d_jobs, d_res, cs));
             const size_t a = step_off[k], cnt = step_off[k + 1] - a;
-            if (cnt) RCOK(lzf_decompress_batch(d_jobs + a, d_res + a, (uint32_t)cnt, cs));
+            if (cnt) {
+                uint64_t max_in = 0;                                                       // (the host built the jobs: it knows their sizes)
+                for (size_t q = a; q < a + cnt; ++q) if (jobs[q].input_len > max_in) max_in = jobs[q].input_len;
+                RCOK(lzf_decompress_batch_sized(d_jobs + a, d_res + a, (uint32_t)cnt, max_in, cs));
+            }
         }
         if (n_jobs) HIPOK(hipMemcpyAsync(mbox, d_res, sizeof(lzf_job_result) * n_jobs, hipMemcpyDeviceToHost, cs));
     } else {
