@@ -223,6 +223,126 @@ __global__ __launch_bounds__(64) void lzf_seg_parse_kernel(seg_ctx c) {
             constexpr int mode = decltype(MODE)::value;
             const uint32_t stop = go ? (end_r < fe ? end_r : fe) : 0u;
             for (;;) {
+#ifndef LZF_SEG_NOASM
+                // ---- plain hops, hand-scheduled (the walks are chains of dependent instructions: every one counts; hipcc's version of
+                //      this loop spends ~20 scalar instructions per hop on lane masks).  exec stays full; a lane is in the loop while
+                //      lim != 0 and leaves by lim = 0 when its hop is not a plain one: past the stop position, parked for the general
+                //      routine, on a token marked in row A (mode 1), or because the previous token's match length turned out to go on
+                //      (0xFF extension byte: r steps back to that token, which the general routine then takes).
+                {
+                    uint32_t mxp = 0, rprev = r, lim = (go && !merged && r < stop) ? stop : 0u, mg = merged ? 1u : 0u;
+                    uint32_t a_, w_, t_, x_, rn_, mxn_, y_, mk_;
+                    unsigned long long sgo, sy;
+                    const uint32_t rowa = lds_addr(rowsA) + lane * 4u, rowd = lds_addr(rowsB) - lds_addr(rowsA);
+                    if (mode == 0) {
+                        asm volatile(
+                            "Lw%=:\n\t"
+                            "v_cmp_ne_u32 vcc, 0, %[lim]\n\t"
+                            "s_cbranch_vccz Ld%=\n\t"
+                            "v_cndmask_b32 %[a], 0, %[r], vcc\n\t"
+                            "v_add_u32 %[a], %[cbm1], %[a]\n\t"
+                            "ds_read_b32 %[w], %[a]\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "v_and_b32 %[t], 0xff, %[w]\n\t"
+                            "v_cmp_eq_u32 vcc, 0xff, %[t]\n\t"
+                            "v_cndmask_b32 %[t], 0, %[mxp], vcc\n\t"
+                            "v_cmp_ne_u32 vcc, 0, %[t]\n\t"
+                            "v_cndmask_b32 %[r], %[r], %[rprev], vcc\n\t"
+                            "v_cndmask_b32_e64 %[lim], %[lim], 0, vcc\n\t"
+                            "v_cmp_lt_u32_e64 %[sgo], %[r], %[lim]\n\t"
+                            "v_bfe_u32 %[x], %[w], 12, 4\n\t"
+                            "v_bfe_u32 %[t], %[w], 16, 8\n\t"
+                            "v_cmp_eq_u32 vcc, 15, %[x]\n\t"
+                            "v_cndmask_b32 %[t], 0, %[t], vcc\n\t"
+                            "v_addc_co_u32 %[rn], vcc, %[x], %[t], vcc\n\t"
+                            "v_add3_u32 %[rn], %[rn], %[r], 3\n\t"
+                            "v_bfe_u32 %[x], %[w], 8, 4\n\t"
+                            "v_cmp_eq_u32 vcc, 15, %[x]\n\t"
+                            "v_cndmask_b32 %[mxn], 0, 1, vcc\n\t"
+                            "v_add_u32 %[rn], %[rn], %[mxn]\n\t"
+                            "v_and_b32 %[t], 0xfff000, %[w]\n\t"
+                            "v_cmp_ne_u32 vcc, 0xfff000, %[t]\n\t"
+                            "v_cmp_gt_u32_e64 %[sy], %[fe], %[rn]\n\t"
+                            "s_and_b64 vcc, vcc, %[sy]\n\t"
+                            "s_and_b64 vcc, vcc, %[sgo]\n\t"
+                            "v_sub_u32 %[t], %[r], %[rb0]\n\t"
+                            "v_cndmask_b32 %[t], 0, %[t], vcc\n\t"
+                            "v_lshrrev_b32 %[x], 5, %[t]\n\t"
+                            "v_lshl_add_u32 %[x], %[x], 8, %[rowa]\n\t"
+                            "v_cndmask_b32 %[a], 0, 1, vcc\n\t"
+                            "v_lshlrev_b32 %[a], %[t], %[a]\n\t"
+                            "ds_or_b32 %[x], %[a]\n\t"
+                            "v_cndmask_b32 %[rprev], %[rprev], %[r], vcc\n\t"
+                            "v_cndmask_b32 %[r], %[r], %[rn], vcc\n\t"
+                            "v_cndmask_b32 %[mxp], 0, %[mxn], vcc\n\t"
+                            "v_cndmask_b32 %[lim], 0, %[lim], vcc\n\t"
+                            "s_branch Lw%=\n"
+                            "Ld%=:"
+                            : [r] "+v"(r), [rprev] "+v"(rprev), [mxp] "+v"(mxp), [lim] "+v"(lim),
+                              [a] "=&v"(a_), [w] "=&v"(w_), [t] "=&v"(t_), [x] "=&v"(x_), [rn] "=&v"(rn_), [mxn] "=&v"(mxn_), [sgo] "=&s"(sgo), [sy] "=&s"(sy)
+                            : [cbm1] "s"(cbuf_a - 1u), [fe] "s"(fe), [rb0] "v"(rb0), [rowa] "v"(rowa)
+                            : "vcc", "memory");
+                    } else {
+                        asm volatile(
+                            "Lw%=:\n\t"
+                            "v_cmp_ne_u32 vcc, 0, %[lim]\n\t"
+                            "s_cbranch_vccz Ld%=\n\t"
+                            "v_cndmask_b32 %[a], 0, %[r], vcc\n\t"
+                            "v_sub_u32 %[y], %[r], %[rb0]\n\t"
+                            "v_add_u32 %[a], %[cbm1], %[a]\n\t"
+                            "v_cndmask_b32 %[y], 0, %[y], vcc\n\t"
+                            "ds_read_b32 %[w], %[a]\n\t"
+                            "v_lshrrev_b32 %[x], 5, %[y]\n\t"
+                            "v_lshl_add_u32 %[x], %[x], 8, %[rowa]\n\t"
+                            "ds_read_b32 %[mk], %[x]\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "v_lshrrev_b32 %[mk], %[y], %[mk]\n\t"
+                            "v_and_b32 %[mk], 1, %[mk]\n\t"
+                            "v_and_b32 %[t], 0xff, %[w]\n\t"
+                            "v_cmp_eq_u32 vcc, 0xff, %[t]\n\t"
+                            "v_cndmask_b32 %[t], 0, %[mxp], vcc\n\t"
+                            "v_cmp_ne_u32 vcc, 0, %[t]\n\t"
+                            "v_cndmask_b32 %[r], %[r], %[rprev], vcc\n\t"
+                            "v_cndmask_b32_e64 %[lim], %[lim], 0, vcc\n\t"
+                            "v_cmp_lt_u32_e64 %[sgo], %[r], %[lim]\n\t"
+                            "v_cmp_ne_u32 vcc, 0, %[mk]\n\t"
+                            "s_and_b64 vcc, vcc, %[sgo]\n\t"
+                            "v_cndmask_b32_e64 %[mg], %[mg], 1, vcc\n\t"
+                            "s_andn2_b64 %[sgo], %[sgo], vcc\n\t"
+                            "v_bfe_u32 %[mk], %[w], 12, 4\n\t"
+                            "v_bfe_u32 %[t], %[w], 16, 8\n\t"
+                            "v_cmp_eq_u32 vcc, 15, %[mk]\n\t"
+                            "v_cndmask_b32 %[t], 0, %[t], vcc\n\t"
+                            "v_addc_co_u32 %[rn], vcc, %[mk], %[t], vcc\n\t"
+                            "v_add3_u32 %[rn], %[rn], %[r], 3\n\t"
+                            "v_bfe_u32 %[mk], %[w], 8, 4\n\t"
+                            "v_cmp_eq_u32 vcc, 15, %[mk]\n\t"
+                            "v_cndmask_b32 %[mxn], 0, 1, vcc\n\t"
+                            "v_add_u32 %[rn], %[rn], %[mxn]\n\t"
+                            "v_and_b32 %[t], 0xfff000, %[w]\n\t"
+                            "v_cmp_ne_u32 vcc, 0xfff000, %[t]\n\t"
+                            "v_cmp_gt_u32_e64 %[sy], %[fe], %[rn]\n\t"
+                            "s_and_b64 vcc, vcc, %[sy]\n\t"
+                            "s_and_b64 vcc, vcc, %[sgo]\n\t"
+                            "v_add_u32 %[x], %[x], %[rowd]\n\t"                 /* the same word of row B */
+                            "v_cndmask_b32 %[a], 0, 1, vcc\n\t"
+                            "v_lshlrev_b32 %[a], %[y], %[a]\n\t"
+                            "ds_or_b32 %[x], %[a]\n\t"
+                            "v_cndmask_b32 %[rprev], %[rprev], %[r], vcc\n\t"
+                            "v_cndmask_b32 %[r], %[r], %[rn], vcc\n\t"
+                            "v_cndmask_b32 %[mxp], 0, %[mxn], vcc\n\t"
+                            "v_cndmask_b32 %[lim], 0, %[lim], vcc\n\t"
+                            "s_branch Lw%=\n"
+                            "Ld%=:"
+                            : [r] "+v"(r), [rprev] "+v"(rprev), [mxp] "+v"(mxp), [lim] "+v"(lim), [mg] "+v"(mg),
+                              [a] "=&v"(a_), [w] "=&v"(w_), [t] "=&v"(t_), [x] "=&v"(x_), [rn] "=&v"(rn_), [mxn] "=&v"(mxn_), [y] "=&v"(y_), [mk] "=&v"(mk_),
+                              [sgo] "=&s"(sgo), [sy] "=&s"(sy)
+                            : [cbm1] "s"(cbuf_a - 1u), [fe] "s"(fe), [rb0] "v"(rb0), [rowa] "v"(rowa), [rowd] "v"(rowd)
+                            : "vcc", "memory");
+                    }
+                    merged = mg != 0u;
+                }
+#else
                 uint32_t mxp = 0, rprev = r;
                 bool act = go && !merged && r < stop;
                 while (__any(act)) {
@@ -251,6 +371,7 @@ __global__ __launch_bounds__(64) void lzf_seg_parse_kernel(seg_ctx c) {
                         }
                     }
                 }
+#endif
                 // the general routine serves parked lanes and lanes near the end of the input
                 const uint32_t pa = cstart + r;
                 const bool slow = go && !merged && r < end_r && pa < len;
