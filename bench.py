@@ -460,7 +460,7 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
                                   "frac": round(c_achieved / HBM_PEAK_GBS, 5), "traffic": c_traffic,
                                   "algorithmic_bytes_per_launch": c_bytes, "kernel_ms": round(c_kernel_ms, 3)}},
         # the same call at smaller batch sizes (compressed blocks of the first 1 / 4 / 20 copies; kernel time by HIP events,
-        # median of 5): up to 768 blocks go through the segmented pipeline, a block decoded by many wavefronts
+        # median of 5): up to 1024 blocks go through the segmented pipeline, a block decoded by many wavefronts
         "batch_sweep": sweep,
         "cpu_baseline": cpu,
         "end_to_end": e2e,

@@ -135,7 +135,7 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
 int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_results,
                          uint32_t n_jobs, void* hip_stream);
 /* The same with what the caller knows about the batch: an upper bound of the jobs' input_len (the job array lives in HBM, the
- * library cannot look; ~0 = unknown, which is what lzf_decompress_batch passes).  Batches of up to three blocks per CU go through the
+ * library cannot look; ~0 = unknown, which is what lzf_decompress_batch passes).  Batches of up to four blocks per CU go through the
  * segmented pipeline (a block decoded by many wavefronts; blocks of 64 KiB .. 4 MiB + 32 KiB of input without prefix / existing
  * output), whose stream-ordered scratch — bit maps, tile sums and a 16-byte record per sequence, up to ~0.15 + 1.8 bytes per byte of
  * `max_input_len` and job, from the device's default memory pool, freed in stream order — is sized by this bound; with a bound below
@@ -143,7 +143,7 @@ int lzf_decompress_batch(const lzf_decompress_job* d_jobs, lzf_job_result* d_res
 int lzf_decompress_batch_sized(const lzf_decompress_job* d_jobs, lzf_job_result* d_results,
                                uint32_t n_jobs, uint64_t max_input_len, void* hip_stream);
 /* Diagnostic: the kernels the calling thread's last lzf_decompress_batch launched (the batch size picks them: the
- * segmented pipeline — one block decoded by many wavefronts — up to three blocks per CU, one workgroup per block beyond). */
+ * segmented pipeline — one block decoded by many wavefronts — up to four blocks per CU, one workgroup per block beyond). */
 const char* lzf_last_decompress_launch(void);
 
 /* EncoderTable helpers on device tables.
