@@ -134,7 +134,7 @@ bool seg_alloc(SegScratch& s, const lzf_decompress_job* d_jobs, lzf_job_result* 
 inline uint32_t seg_grid(uint32_t target, uint32_t n, uint32_t cap) {
     uint32_t g = target / n; if (g < 1u) g = 1u; if (g > cap) g = cap; return g;
 }
-// stages: 1 plan, 2 parse, 3 seam, 4 tilesum, 5 scan, 6 records, 7 levels, 8 resolve (all when upto >= 8)
+// stages: 1 plan, 2 parse, 3 seam, 4 tilesum, 5 scan, 6 records (+ levels), 8 resolve (all when upto >= 8)
 int seg_launch(const lzf::seg_ctx& c, uint32_t upto, hipStream_t st) {
     const uint32_t n = c.n_jobs;
     LAUNCH(lzf::lzf_seg_plan_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, c);
@@ -143,7 +143,6 @@ int seg_launch(const lzf::seg_ctx& c, uint32_t upto, hipStream_t st) {
     if (upto >= 4) LAUNCH(lzf::lzf_seg_tilesum_kernel, dim3(seg_grid(32768u, n, c.maxtile), n), dim3(64), 0, st, c);
     if (upto >= 5) LAUNCH(lzf::lzf_seg_scan_kernel, dim3(n), dim3(64), 0, st, c);
     if (upto >= 6) LAUNCH(lzf::lzf_seg_records_kernel, dim3(seg_grid(32768u, n, c.maxtile), n), dim3(64), 0, st, c);
-    if (upto >= 7) LAUNCH(lzf::lzf_seg_levels_kernel, dim3(seg_grid(32768u, n, 16384u), n), dim3(64), 0, st, c);
     if (upto >= 8) {
         if (c.ring_bytes == 131072u) LAUNCH(lzf::lzf_seg_resolve_pair_kernel<131072>, dim3(n), dim3(128), 0, st, c);
         else if (c.ring_bytes == 65536u) LAUNCH(lzf::lzf_seg_resolve_pair_kernel<65536>, dim3(n), dim3(128), 0, st, c);

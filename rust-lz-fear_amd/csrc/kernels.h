@@ -98,10 +98,9 @@ LZF_V6_VARIANTS(LZF_EXT6)
 //             overlap), otherwise a short walk patches the bit map
 //   tilesum   one wave per 2 KiB tile of compressed bytes: tokens and output bytes of the tile
 //   scan      one wave per job: exclusive sums over the tiles, record space from the arena
-//   records   one wave per tile: decode every token, absolute output positions, error checks, LITERALS -> out,
-//             one 16-byte record per sequence {lo, mo, M, off}
-//   levels    one wave per 64 records: dependency level of every match inside its batch (level k copies only from
-//             bytes that are final once levels < k are done)
+//   records   one wave per tile: decode every token, absolute output positions, error checks, LITERALS -> out, and per
+//             batch of 64 sequences the dependency level of every match (level k copies only from bytes that are final
+//             once levels < k are done), its sub-batch and length class: one 16-byte record per sequence, final form
 //   resolve   one wave per job, the only serial stage: ring of the recent output in LDS (filled with the literals
 //             already in place), per batch one LDS round per dependency level, flush with aligned 16-byte stores
 // A job that is not eligible, or in which any stage meets something it does not handle (every DecodeError, capacity,
@@ -136,7 +135,6 @@ __global__ void lzf_seg_seam_kernel(seg_ctx c);
 __global__ void lzf_seg_tilesum_kernel(seg_ctx c);
 __global__ void lzf_seg_scan_kernel(seg_ctx c);
 __global__ void lzf_seg_records_kernel(seg_ctx c);
-__global__ void lzf_seg_levels_kernel(seg_ctx c);
 template <int R>
 __global__ void lzf_seg_resolve_pair_kernel(seg_ctx c);
 extern template __global__ void lzf_seg_resolve_pair_kernel<32768>(seg_ctx);

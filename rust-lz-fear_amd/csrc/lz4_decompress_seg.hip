@@ -656,7 +656,8 @@ __global__ __launch_bounds__(64) void lzf_seg_tilesum_kernel(seg_ctx c) {
         const uint64_t tot = (uint64_t)__builtin_amdgcn_readlane(wave_scan_add(sum & 0xFFFFu), 63) +
                              ((uint64_t)__builtin_amdgcn_readlane(wave_scan_add(sum >> 16), 63) << 16);
         if (tot > 0x7FFFFFFFull) err = true;
-        if (lane == 0u) { c.tile_tok[(size_t)j * c.maxtile + t] = n; c.tile_out[(size_t)j * c.maxtile + t] = (uint32_t)tot; }
+        // (records are kept in batches of 64 that never span tiles: a tile's tokens take ceil(n / 64) batches, the last one padded)
+        if (lane == 0u) { c.tile_tok[(size_t)j * c.maxtile + t] = (n + 63u) / 64u; c.tile_out[(size_t)j * c.maxtile + t] = (uint32_t)tot; }
         if (__ballot(err) && lane == 0u) c.st[j].failed = 1u;
     }
 }
@@ -686,10 +687,11 @@ __global__ __launch_bounds__(64) void lzf_seg_scan_kernel(seg_ctx c) {
     }
     if (lane == 0u) {
         const uint64_t cap = job.out_cap > kMaxPosB ? kMaxPosB : job.out_cap;
+        ctok *= 64ull;                                                           // batches -> records (padded)
         bool ok = cout <= cap && ctok < 0x7FFFFFFFull;
         uint64_t off = 0;
         if (ok) {
-            const uint64_t need = (ctok + 63ull) / 64ull * 64ull + 64ull;
+            const uint64_t need = ctok + 64ull;
             off = atomicAdd(c.rec_top, (unsigned long long)need);
             if (off + need > c.rec_cap) ok = false;
         }
@@ -698,10 +700,25 @@ __global__ __launch_bounds__(64) void lzf_seg_scan_kernel(seg_ctx c) {
     }
 }
 
-// records + literals
+// =====================================================================================================================
+// records + literals + levels: everything the resolve stage needs to know about a sequence, so that its two wavefronts
+// compute nothing of it themselves
+// =====================================================================================================================
+// Per batch of 64 tokens of a tile (batches never span tiles; the last one of a tile is padded with empty sequences):
+// decode (decompress.rs:61-74), absolute positions, the checks of :72-74,:83-89, LITERALS -> out, then
+// level(j) = 1 + max level of the matches (of the same batch) whose destination overlaps j's source bytes; 1 when there
+// are none (everything in front of the batch is final when the batch starts).  Destinations are disjoint and in stream
+// order, so the matches j depends on are a range of lanes [i_lo, i_hi], found by two binary searches; ranges wider than
+// two lanes use the running maximum up to i_hi (never too small: a larger level is only later, not wrong).
+// Record:  w0 = M,  w1 = biased destination (mo + rb, rb = out & 15),  w2 = sub-batch (0..63) | level << 16 | class << 24,  w3 = off.
+// Sub-batches: consecutive sequences of the batch whose output spans at most ring / 8 bytes (greedy).
+// Classes: 0 no match | 1: 4..7 bytes | 2: 8..16 | 3: 17..32 | 4: 33..64 (all not overlapping, source inside the ring) |
+//   5 overlapping, <= 64 | 6 whole wave (longer, or wrapping around the ring) | 7 source (partly) older than what the ring
+//   is guaranteed to hold when the sub-batch is resolved: moved by the stager | 8 a sequence larger than a sub-batch.
 __global__ __launch_bounds__(64) void lzf_seg_records_kernel(seg_ctx c) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kTileStage];
     __shared__ uint16_t list[kTileTokMax + 64u];
+    __shared__ uint32_t s_end[64], s_mo[64], s_lvl[64], s_pm[64];
     const uint32_t j = blockIdx.y;
     const seg_job sj = c.st[j];
     if (!sj.eligible || sj.failed) return;
@@ -713,19 +730,23 @@ __global__ __launch_bounds__(64) void lzf_seg_records_kernel(seg_ctx c) {
     const uint32_t cap = job.out_cap > kMaxPosB ? kMaxPosB : (uint32_t)job.out_cap;
     const uint64_t limit = job.output_limit;
     LZF_GLOBAL u32x4* const recs = (LZF_GLOBAL u32x4*)c.recs + sj.rec_off;
+    const uint32_t R = c.ring_bytes, kSpan = R / 8u, kAheadB = 3u * kSpan + 64u;
+    const uint32_t rb = (uint32_t)(reinterpret_cast<uintptr_t>(job.out) & 15u);
     for (uint32_t t = blockIdx.x; t < sj.ntile; t += gridDim.x) {
         __syncthreads();
         const uint32_t n = tile_enumerate(c, j, t, lane, len, in, stage, list);
         TileCtx tc{t * kSegTile, lds_addr(stage), len, in};
-        const uint32_t tbase = c.tile_tok[(size_t)j * c.maxtile + t];
+        const uint32_t tbase = c.tile_tok[(size_t)j * c.maxtile + t] * 64u;         // first record of the tile (its batches are padded to 64)
         uint32_t obase = c.tile_out[(size_t)j * c.maxtile + t];
         bool bad = false;
         for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
-            const bool act = i0 + lane < n;
+            const uint32_t nb = n - i0 < 64u ? n - i0 : 64u;
+            const bool act = lane < nb;
             Tok k; k.L = 0; k.M = 0; k.off = 0; k.src = 0; k.err = false;
             if (act) k = tile_decode(tc, tc.tstart + list[i0 + lane]);
             const uint32_t tot = k.L + k.M;
             const uint32_t incl = wave_scan_add(tot);
+            const uint32_t ob = obase;
             const uint32_t lo = obase + (incl - tot), mo = lo + k.L;
             obase += __builtin_amdgcn_readlane(incl, 63);
             bool ok = act && !k.err;
@@ -735,8 +756,6 @@ __global__ __launch_bounds__(64) void lzf_seg_records_kernel(seg_ctx c) {
             }
             bad = bad || (act && !ok);
             if (ok) {
-                u32x4 r; r[0] = lo; r[1] = mo; r[2] = k.M; r[3] = k.off;
-                recs[tbase + i0 + lane] = r;
                 if (k.L > 0u && k.L <= 64u) copy_small_gg(out + lo, in + k.src, k.L);       // literals :65-67
                 else if (k.L > 64u && k.L <= 256u) copy_medium_gg(out + lo, in + k.src, k.L);
             }
@@ -744,113 +763,85 @@ __global__ __launch_bounds__(64) void lzf_seg_records_kernel(seg_ctx c) {
                 const uint32_t q = (uint32_t)__builtin_ctzll(m);
                 wave_copy_long(out + __builtin_amdgcn_readlane(lo, q), in + __builtin_amdgcn_readlane(k.src, q), __builtin_amdgcn_readlane(k.L, q), lane);
             }
+            if (__ballot(bad)) continue;                                                      // (the job is not ours any more: no records needed)
+            // ---- levels: which matches of the batch copy from which (see the head of this section)
+            const uint32_t M = k.M, off = k.off;
+            const bool has = act && M != 0u;
+            const uint32_t span = M < off ? M : off;
+            const uint32_t s0 = mo - off, e0 = s0 + span;
+            __syncthreads();
+            s_end[lane] = act ? mo + M : 0xFFFFFFFFu;
+            s_mo[lane] = act ? mo : 0xFFFFFFFFu;
+            uint32_t lvl = has ? 1u : 0u;
+            const bool dep = has && e0 > ob;             // the source reaches into the batch
+            uint32_t ilo = 0, ihi = 0; bool any_dep = false;
+            if (__any(dep)) {
+                __syncthreads();
+                uint32_t a = 0, bb = 0;                   // a = #lanes with end <= s0; bb = #lanes with mo < e0
+#pragma unroll
+                for (uint32_t step = 32u; step; step >>= 1) {
+                    if (s_end[(a + step - 1u) & 63u] <= s0) a += step;
+                    if (s_mo[(bb + step - 1u) & 63u] < e0) bb += step;
+                }
+                ilo = a; ihi = bb - 1u;
+                any_dep = dep && bb >= 1u && ilo <= ihi && ihi < lane;
+            }
+            if (__any(any_dep)) {
+                for (uint32_t it = 0; it < 64u; ++it) {
+                    __syncthreads();
+                    s_lvl[lane] = lvl;
+                    s_pm[lane] = wave_scan_max(lvl);
+                    __syncthreads();
+                    uint32_t nl = lvl;
+                    if (any_dep) {
+                        const uint32_t m = ihi - ilo <= 1u ? (s_lvl[ilo] > s_lvl[ihi] ? s_lvl[ilo] : s_lvl[ihi]) : s_pm[ihi];
+                        nl = 1u + m;
+                    }
+                    const bool ch = nl != lvl;
+                    lvl = nl;
+                    if (!__any(ch)) break;
+                }
+            }
+            // ---- sub-batches and classes
+            const uint32_t endp = mo + M;
+            uint32_t sub = 0, cls = 0;
+            uint32_t a = 0, sidx = 0;
+            while (a < nb) {
+                const uint32_t sob = __builtin_amdgcn_readlane(lo, a);
+                const uint32_t bb0 = first_lane(__ballot(lane >= a && lane < nb && endp - sob > kSpan));
+                uint32_t e = bb0 < nb ? bb0 : nb;
+                const bool giant = e == a;
+                if (giant) e = a + 1u;
+                const uint32_t oe = __builtin_amdgcn_readlane(endp, e - 1u);
+                if (lane >= a && lane < e) {
+                    sub = sidx;
+                    if (giant) cls = 8u;
+                    else if (M != 0u) {
+                        // what the ring holds for certain when this sub-batch is resolved: from fill pointer + fetch-ahead - ring on
+                        const uint32_t fpw = ((oe + rb + 15u) & ~15u) + kAheadB;
+                        const uint32_t lov = fpw > R ? fpw - R : 0u;
+                        const uint32_t sy = s0 + rb, dy = mo + rb;
+                        const uint32_t di = dy & (R - 1u), si = sy & (R - 1u);
+                        const bool wrap = di + M > R || si + M > R;
+                        if (sy < lov) cls = 7u;
+                        else if (M > 64u || wrap) cls = 6u;
+                        else if (off < M) cls = 5u;
+                        else cls = M < 8u ? 1u : M <= 16u ? 2u : M <= 32u ? 3u : 4u;
+                    }
+                }
+                a = e; ++sidx;
+            }
+            // ---- the records of the batch; the lanes behind the tile's last token pad it (an empty sequence at the batch's end)
+            {
+                const uint32_t last_end = __builtin_amdgcn_readlane(endp, (nb - 1u) & 63u);
+                const uint32_t last_sub = __builtin_amdgcn_readlane(sub, (nb - 1u) & 63u);
+                u32x4 w;
+                w[0] = act ? M : 0u; w[1] = (act ? mo : last_end) + rb;
+                w[2] = (act ? sub : last_sub) | ((act ? lvl : 0u) << 16) | ((act ? cls : 0u) << 24); w[3] = act ? off : 0u;
+                recs[tbase + i0 + lane] = w;
+            }
         }
         if (__ballot(bad) && lane == 0u) c.st[j].failed = 1u;
-    }
-}
-
-// =====================================================================================================================
-// levels: within a batch of 64 records, which matches copy from which — and everything else the resolve stage needs to
-// know about a record, so that its two wavefronts compute nothing of it themselves
-// =====================================================================================================================
-// level(j) = 1 + max level of the matches (of the same batch) whose destination overlaps j's source bytes; 1 when there
-// are none (everything in front of the batch is final when the batch starts).  Destinations are disjoint and in stream
-// order, so the matches j depends on are a range of lanes [i_lo, i_hi], found by two binary searches; ranges wider than
-// two lanes use the running maximum up to i_hi (never too small: a larger level is only later, not wrong).
-// Output record (replaces {lo, mo, M, off}):  w0 = M,  w1 = biased destination (mo + rb, rb = out & 15),
-//   w2 = sub-batch (0..63) | level << 16 | class << 24,  w3 = off.
-// Sub-batches: consecutive sequences of the batch whose output spans at most ring / 8 bytes (greedy).
-// Classes: 0 no match | 1: 4..7 bytes | 2: 8..16 | 3: 17..32 | 4: 33..64 (all not overlapping, source inside the ring) |
-//   5 overlapping, <= 64 | 6 whole wave (longer, or wrapping around the ring) | 7 source (partly) older than what the ring
-//   is guaranteed to hold when the sub-batch is resolved: moved by the stager | 8 a sequence larger than a sub-batch.
-__global__ __launch_bounds__(64) void lzf_seg_levels_kernel(seg_ctx c) {
-    __shared__ uint32_t s_end[64], s_mo[64], s_lvl[64], s_pm[64];
-    const uint32_t j = blockIdx.y;
-    const seg_job sj = c.st[j];
-    if (!sj.eligible || sj.failed) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    LZF_GLOBAL u32x4* const recs = (LZF_GLOBAL u32x4*)c.recs + sj.rec_off;
-    const uint32_t nb_all = (sj.ntok + 63u) / 64u;
-    const uint32_t R = c.ring_bytes, kSpan = R / 8u, kAheadB = 3u * kSpan + 64u;
-    const uint32_t rb = (uint32_t)(reinterpret_cast<uintptr_t>(c.jobs[j].out) & 15u);
-    for (uint32_t b = blockIdx.x; b < nb_all; b += gridDim.x) {
-        const uint32_t idx = b * 64u + lane;
-        const uint32_t nb = sj.ntok - b * 64u < 64u ? sj.ntok - b * 64u : 64u;
-        const bool act = lane < nb;
-        u32x4 r = u32x4{0, 0, 0, 0};
-        if (act) r = recs[idx];
-        const uint32_t lo = r[0], mo = r[1], M = r[2], off = r[3] & 0xFFFFu;
-        const bool has = act && M != 0u;
-        const uint32_t span = M < off ? M : off;
-        const uint32_t s0 = mo - off, e0 = s0 + span;
-        const uint32_t ob = __builtin_amdgcn_readlane(lo, 0);
-        __syncthreads();
-        s_end[lane] = act ? mo + M : 0xFFFFFFFFu;
-        s_mo[lane] = act ? mo : 0xFFFFFFFFu;
-        uint32_t lvl = has ? 1u : 0u;
-        const bool dep = has && e0 > ob;             // the source reaches into the batch
-        uint32_t ilo = 0, ihi = 0; bool any_dep = false;
-        if (__any(dep)) {
-            __syncthreads();
-            // ilo = #lanes with end <= s0; ihi = #lanes with mo < e0, minus 1
-            uint32_t a = 0, bb = 0;
-#pragma unroll
-            for (uint32_t step = 32u; step; step >>= 1) {
-                if (s_end[(a + step - 1u) & 63u] <= s0) a += step;
-                if (s_mo[(bb + step - 1u) & 63u] < e0) bb += step;
-            }
-            ilo = a; ihi = bb - 1u;
-            any_dep = dep && bb >= 1u && ilo <= ihi && ihi < lane;
-        }
-        if (__any(any_dep)) {
-            for (uint32_t it = 0; it < 64u; ++it) {
-                __syncthreads();
-                s_lvl[lane] = lvl;
-                s_pm[lane] = wave_scan_max(lvl);
-                __syncthreads();
-                uint32_t nl = lvl;
-                if (any_dep) {
-                    const uint32_t m = ihi - ilo <= 1u ? (s_lvl[ilo] > s_lvl[ihi] ? s_lvl[ilo] : s_lvl[ihi]) : s_pm[ihi];
-                    nl = 1u + m;
-                }
-                const bool ch = nl != lvl;
-                lvl = nl;
-                if (!__any(ch)) break;
-            }
-        }
-        // ---- sub-batches and classes
-        const uint32_t endp = mo + M;
-        uint32_t sub = 0, cls = 0;
-        uint32_t a = 0, sidx = 0;
-        while (a < nb) {
-            const uint32_t sob = __builtin_amdgcn_readlane(lo, a);
-            const uint32_t bb0 = first_lane(__ballot(lane >= a && lane < nb && endp - sob > kSpan));
-            uint32_t e = bb0 < nb ? bb0 : nb;
-            const bool giant = e == a;
-            if (giant) e = a + 1u;
-            const uint32_t oe = __builtin_amdgcn_readlane(endp, e - 1u);
-            if (lane >= a && lane < e) {
-                sub = sidx;
-                if (giant) cls = 8u;
-                else if (M != 0u) {
-                    // what the ring holds for certain when this sub-batch is resolved: from fill pointer + fetch-ahead - ring on
-                    const uint32_t fpw = ((oe + rb + 15u) & ~15u) + kAheadB;
-                    const uint32_t lov = fpw > R ? fpw - R : 0u;
-                    const uint32_t sy = s0 + rb, dy = mo + rb;
-                    const uint32_t di = dy & (R - 1u), si = sy & (R - 1u);
-                    const bool wrap = di + M > R || si + M > R;
-                    if (sy < lov) cls = 7u;
-                    else if (M > 64u || wrap) cls = 6u;
-                    else if (off < M) cls = 5u;
-                    else cls = M < 8u ? 1u : M <= 16u ? 2u : M <= 32u ? 3u : 4u;
-                }
-            }
-            a = e; ++sidx;
-        }
-        if (act) {
-            u32x4 w; w[0] = M; w[1] = mo + rb; w[2] = sub | (lvl << 16) | (cls << 24); w[3] = off;
-            recs[idx] = w;
-        }
     }
 }
 
@@ -1134,9 +1125,11 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                 if (!msub) { gave_up = true; if (lane == 0u) flag_set(3, 1u); break; }      // (records that do not number their sub-batches 0, 1, 2 ...: not ours)
                 const uint32_t last = 63u - (uint32_t)__builtin_clzll(msub);
                 const uint32_t oe = __builtin_amdgcn_readlane(endy, last);      // biased end of the sub-batch
-                if (__ballot(sub == s_i && cls == 8u)) {
+                if (const unsigned long long mg8 = __ballot(sub == s_i && cls == 8u)) {
                     // ---- a sequence larger than a sub-batch: everything in front of it resolved and in HBM, then HBM -> HBM
-                    const uint32_t g_dy = __builtin_amdgcn_readlane(dy, last), g_M = __builtin_amdgcn_readlane(M, last), g_off = __builtin_amdgcn_readlane(off, last);
+                    // (it is alone in its sub-batch but for the empty sequences that pad a tile's last batch)
+                    const uint32_t gl = (uint32_t)__builtin_ctzll(mg8);
+                    const uint32_t g_dy = __builtin_amdgcn_readlane(dy, gl), g_M = __builtin_amdgcn_readlane(M, gl), g_off = __builtin_amdgcn_readlane(off, gl);
                     wait_resolved(ticket);
                     flush_resolved(ticket);
                     if (fp < ((prev_end + 15u) & ~15u)) fill_to((prev_end + 15u) & ~15u);

@@ -136,51 +136,60 @@ def run(blocks, min_in, upto, verbose=True):
             if len(diff):
                 p = int(diff[0]); h = 0 if p < CHUNK else 1 + (p - CHUNK) // STRIDE
                 msgs.append(f"token map differs at {len(diff)} positions, first {p} (truth {truth[p]}, chunk {h}, vfrom {vfrom[i, h]:#x}, x[h-1] {xexit[i, h - 1] if h else 0})")
+        # records live in batches of 64 that never span 2 KiB tiles of the input: a tile's tokens, then padding
+        slots = []                                   # index into toks, or None (padding)
+        k0 = 0
+        ntile = (len(cdat) + TILE - 1) // TILE
+        for t in range(ntile):
+            k1 = k0
+            while k1 < len(toks) and toks[k1][0] < (t + 1) * TILE:
+                k1 += 1
+            slots.extend(range(k0, k1)); slots.extend([None] * ((-(k1 - k0)) % 64))
+            k0 = k1
         if upto >= 5 and not s["failed"]:
-            if int(s["ntok"]) != len(toks):
-                msgs.append(f"ntok {s['ntok']} != {len(toks)}")
+            if int(s["ntok"]) != len(slots):
+                msgs.append(f"padded record count {s['ntok']} != {len(slots)}")
             if int(s["outb"]) != len(d):
                 msgs.append(f"outb {s['outb']} != {len(d)}")
-        if upto >= 6 and not s["failed"] and int(s["ntok"]) == len(toks):
-            r = recs[int(s["rec_off"]):int(s["rec_off"]) + len(toks)]
+        if upto >= 6 and not s["failed"] and int(s["ntok"]) == len(slots):
+            r = recs[int(s["rec_off"]):int(s["rec_off"]) + len(slots)]
+            rbias = (int(dout.data_ptr()) + int(out_off[i])) & 15
             lo = 0
-            exp = np.zeros((len(toks), 4), np.uint32)
-            for k, (pos, L, M, off, src) in enumerate(toks):
-                exp[k] = (lo, lo + L, M, off); lo += L + M
-            if upto >= 7:       # the levels stage rewrites a record as {M, biased destination, sub | level << 16 | class << 24, off}
-                rbias = (int(dout.data_ptr()) + int(out_off[i])) & 15
-                r = np.stack([r[:, 1] - rbias - (exp[:, 1] - exp[:, 0]), r[:, 1] - rbias, r[:, 0], (r[:, 3] & 0xFFFF) | (r[:, 2] & 0xFFFF0000)], axis=1).astype(np.uint32)
-            bad = np.nonzero((r[:, :3] != exp[:, :3]).any(axis=1) | ((r[:, 3] & 0xFFFF) != exp[:, 3]))[0]
+            exp = np.zeros((len(slots), 3), np.int64)     # mo, M, off of every slot (padding: the end so far, 0, 0)
+            for q, k in enumerate(slots):
+                if k is None:
+                    exp[q] = (lo, 0, 0)
+                else:
+                    _, L, M, off, _ = toks[k]
+                    exp[q] = (lo + L, M, off); lo += L + M
+            got = np.stack([r[:, 1].astype(np.int64) - rbias, r[:, 0], r[:, 3] & 0xFFFF], axis=1)
+            bad = np.nonzero((got != exp).any(axis=1))[0]
             if len(bad):
-                k = int(bad[0])
-                msgs.append(f"{len(bad)} records differ, first #{k}: got {r[k].tolist()} exp {exp[k].tolist()} (token at {toks[k][0]})")
-            elif upto >= 7:
+                q = int(bad[0])
+                msgs.append(f"{len(bad)} records differ, first slot #{q}: got {got[q].tolist()} exp {exp[q].tolist()}")
+            else:
                 # levels: a match's level must exceed the level of every match of its batch whose destination it reads
-                lv = (r[:, 3] >> 16) & 0xFF
+                lv = (r[:, 2] >> 16) & 0xFF
                 nbad = 0
-                for b0 in range(0, len(toks), 64):
-                    b1 = min(b0 + 64, len(toks))
-                    for k in range(b0, b1):
-                        _, mo, M, off = (int(x) for x in exp[k])
+                for b0 in range(0, len(slots), 64):
+                    for q in range(b0, b0 + 64):
+                        mo, M, off = (int(x) for x in exp[q])
                         if not M:
                             continue
-                        if lv[k] < 1:
+                        if lv[q] < 1:
                             nbad += 1; continue
                         s0 = mo - off; e0 = s0 + min(M, off)
-                        for q in range(b0, k):
-                            qmo, qM = int(exp[q][1]), int(exp[q][2])
-                            if qM and qmo < e0 and qmo + qM > s0 and lv[q] >= lv[k]:
+                        for q2 in range(b0, q):
+                            qmo, qM = int(exp[q2][0]), int(exp[q2][1])
+                            if qM and qmo < e0 and qmo + qM > s0 and lv[q2] >= lv[q]:
                                 nbad += 1
                                 if nbad < 4:
-                                    msgs.append(f"level order broken: #{k} (lvl {lv[k]}) reads #{q} (lvl {lv[q]})")
+                                    msgs.append(f"level order broken: slot {q} (lvl {lv[q]}) reads slot {q2} (lvl {lv[q2]})")
                 if nbad:
                     msgs.append(f"{nbad} level violations")
-                else:
-                    nb = (len(toks) + 63) // 64
-                    mx = [int(lv[b0:b0 + 64].max()) for b0 in range(0, len(toks), 64)]
-                    msgs_info = f"levels ok, mean max level per batch {sum(mx) / nb:.2f}"
-                    if verbose:
-                        print(f"  [{name}] {msgs_info}")
+                elif verbose:
+                    mx = [int(lv[b0:b0 + 64].max()) for b0 in range(0, len(slots), 64)]
+                    print(f"  [{name}] levels ok, mean max level per batch {sum(mx) / max(1, len(mx)):.2f}, {len(slots) - len(toks)} padding slots for {len(toks)} tokens")
         if upto >= 8:
             got = hout[int(out_off[i]):int(out_off[i]) + len(d)].tobytes()
             if s["failed"] or not s["done"]:
