@@ -898,16 +898,18 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
         }
     };
 
-    // ring[d, d + nbytes) <- ring[s, s + nbytes): source final, ranges disjoint; all lanes, 8 bytes each
+    // ring[d, d + nbytes) <- ring[s, s + nbytes): source final, ranges disjoint; all lanes, 8 bytes each, the last unit moved
+    // back to end with the range (it overlaps its neighbour with the same bytes): one LDS round trip per 512 bytes
     auto ring_copy = [&](uint32_t d, uint32_t s_, uint32_t nbytes) {
-        const uint32_t n8 = nbytes >> 3;
-        for (uint32_t u = lane; u < n8; u += kWave) {
-            const uint32_t sa = (s_ + 8u * u) & kMask, da = (d + 8u * u) & kMask;
-            if (sa + 8u <= (uint32_t)R && da + 8u <= (uint32_t)R) lds_st64(ring_a + da, lds_ld64u(ring_a + sa));
-            else for (uint32_t t = 0; t < 8u; ++t) ring[(da + t) & kMask] = ring[(sa + t) & kMask];
-        }
-        const uint32_t t0 = n8 << 3;
-        if (lane < nbytes - t0) ring[(d + t0 + lane) & kMask] = ring[(s_ + t0 + lane) & kMask];
+        if (nbytes >= 8u) {
+            const uint32_t nu = (nbytes + 7u) >> 3;
+            for (uint32_t u = lane; u < nu; u += kWave) {
+                const uint32_t o = 8u * u + 8u <= nbytes ? 8u * u : nbytes - 8u;
+                const uint32_t sa = (s_ + o) & kMask, da = (d + o) & kMask;
+                if (sa + 8u <= (uint32_t)R && da + 8u <= (uint32_t)R) lds_st64(ring_a + da, lds_ld64u(ring_a + sa));
+                else for (uint32_t t = 0; t < 8u; ++t) ring[(da + t) & kMask] = ring[(sa + t) & kMask];
+            }
+        } else if (lane < nbytes) ring[(d + lane) & kMask] = ring[(s_ + lane) & kMask];
     };
     // copy_overlapping (decompress.rs:80-138) inside the ring: out[d + t] = out[d - off + t], t < M.  The bytes already
     // copied double the source every step (a multiple of the period is a period).
@@ -951,15 +953,106 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                 }
                 const unsigned long long msub = nsub == 1u ? ~0ull : __ballot(sub == s_i);
                 unsigned long long todo = (mA_b | m2_b | mS_b) & msub;
+#if defined(LZF_SEG_DBG_SKIP) && LZF_SEG_DBG_SKIP == 2      // analysis: no rounds at all (what a batch costs without them)
+                todo = 0;
+#endif
                 for (uint32_t lv = 1; todo; ++lv) {
-                    const unsigned long long ml = __ballot(lvl == lv) & todo;
+                    unsigned long long ml;
+#if !defined(LZF_SEG_NOASM) && !defined(LZF_SEG_DBG_SKIP)
+                    // The levels whose sequences are all of the two-ended classes, in one hand-scheduled loop: a lone wavefront
+                    // retires an instruction every 5 to 8 cycles, so the round is priced by its instruction count (18 scalar
+                    // instructions + the DS pairs of the classes present; what hipcc makes of the loop below is 45 + 8 EXEC moves).
+                    // It hands a level with a lane of class 5/6 (already taken out of `todo`, in `ml`) to the code below.
+                    {
+                        uint64_t v0, v1, v2, v3, v4, v5, v6, v7; uint32_t va0, va1; unsigned long long sv, ts;
+                        lv = __builtin_amdgcn_readfirstlane(lv);
+                        asm volatile(
+                            "s_mov_b64 %[sv], exec\n\t"
+                            "Lloop%=:\n\t"
+                            "v_cmp_eq_u32_e32 vcc, %[lv], %[vl]\n\t"
+                            "s_add_u32 %[lv], %[lv], 1\n\t"
+                            "s_and_b64 %[ml], vcc, %[todo]\n\t"
+                            "s_cbranch_scc0 Lempty%=\n\t"
+                            "s_andn2_b64 %[todo], %[todo], %[ml]\n\t"
+                            "s_and_b64 %[ts], %[ml], %[mS]\n\t"
+                            "s_cbranch_scc1 Lout%=\n\t"
+#ifdef LZF_SEG_TIME
+                            "s_add_u32 %[nr], %[nr], 1\n\t"
+#endif
+                            "s_and_b64 exec, %[ml], %[mA]\n\t"
+                            "ds_read_b32 %[va0], %[sa]\n\t"
+                            "ds_read_b32 %[va1], %[s1]\n\t"
+                            "s_and_b64 exec, %[ml], %[m2]\n\t"
+                            "ds_read_b64 %[v0], %[sa]\n\t"
+                            "ds_read_b64 %[v3], %[s3]\n\t"
+                            "s_and_b64 exec, %[ml], %[m3]\n\t"
+                            "s_cbranch_execz Lr%=\n\t"
+                            "ds_read_b64 %[v1], %[sa] offset:8\n\t"
+                            "ds_read_b64 %[v2], %[s16]\n\t"
+                            "s_and_b64 exec, %[ml], %[m4]\n\t"
+                            "s_cbranch_execz Lr%=\n\t"
+                            "ds_read_b64 %[v4], %[sa] offset:16\n\t"
+                            "ds_read_b64 %[v5], %[sa] offset:24\n\t"
+                            "ds_read_b64 %[v6], %[s32]\n\t"
+                            "ds_read_b64 %[v7], %[s32] offset:8\n\t"
+                            "Lr%=:\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "s_and_b64 exec, %[ml], %[mA]\n\t"
+                            "ds_write_b32 %[da], %[va0]\n\t"
+                            "ds_write_b32 %[d1], %[va1]\n\t"
+                            "s_and_b64 exec, %[ml], %[m2]\n\t"
+                            "ds_write_b64 %[da], %[v0]\n\t"
+                            "ds_write_b64 %[d3], %[v3]\n\t"
+                            "s_and_b64 exec, %[ml], %[m3]\n\t"
+                            "s_cbranch_execz Lw%=\n\t"
+                            "ds_write_b64 %[da], %[v1] offset:8\n\t"
+                            "ds_write_b64 %[d16], %[v2]\n\t"
+                            "s_and_b64 exec, %[ml], %[m4]\n\t"
+                            "s_cbranch_execz Lw%=\n\t"
+                            "ds_write_b64 %[da], %[v4] offset:16\n\t"
+                            "ds_write_b64 %[da], %[v5] offset:24\n\t"
+                            "ds_write_b64 %[d32], %[v6]\n\t"
+                            "ds_write_b64 %[d32], %[v7] offset:8\n\t"
+                            "Lw%=:\n\t"
+                            "s_mov_b64 exec, %[sv]\n\t"
+                            "s_cmp_lg_u64 %[todo], 0\n\t"
+                            "s_cbranch_scc1 Lloop%=\n\t"
+                            "s_mov_b64 %[ts], 0\n\t"
+                            "s_branch Lout%=\n\t"
+                            "Lempty%=:\n\t"
+                            "s_cmp_le_u32 %[lv], 71\n\t"
+                            "s_cbranch_scc1 Lloop%=\n\t"
+                            "s_mov_b64 %[ts], 0\n\t"
+                            "Lout%=:\n\t"
+                            : [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3), [v4] "=&v"(v4), [v5] "=&v"(v5), [v6] "=&v"(v6), [v7] "=&v"(v7),
+                              [va0] "=&v"(va0), [va1] "=&v"(va1), [sv] "=&s"(sv), [ts] "=&s"(ts), [ml] "=&s"(ml), [todo] "+s"(todo), [lv] "+s"(lv)
+#ifdef LZF_SEG_TIME
+                              , [nr] "+s"(n_rounds)
+#endif
+                            : [mA] "s"(mA_b), [m2] "s"(m2_b), [m3] "s"(m3_b), [m4] "s"(m4_b), [mS] "s"(mS_b), [vl] "v"(lvl),
+                              [sa] "v"(sa), [s1] "v"(sa + a1), [s3] "v"(sa + o3), [s16] "v"(sa + M - 16u), [s32] "v"(sa + M - 32u),
+                              [da] "v"(da), [d1] "v"(da + a1), [d3] "v"(da + o3), [d16] "v"(da + M - 16u), [d32] "v"(da + M - 32u)
+                            : "memory", "vcc", "scc");
+                        RT(tm_asm);
+                        // (hipcc takes what an asm statement returns for divergent, whatever the register class)
+                        auto uni = [](unsigned long long x) { return (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)x) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(x >> 32)) << 32); };
+                        ts = uni(ts); ml = uni(ml); todo = uni(todo); lv = __builtin_amdgcn_readfirstlane(lv);
+                        if (!ts) break;                  // nothing left (or levels that do not end: not our records)
+                        --lv;                            // (the level in `ml`; the loop's increment follows)
+                    }
+#else
+                    ml = __ballot(lvl == lv) & todo;
                     if (!ml) { if (lv > 70u) break; continue; }
                     todo &= ~ml;
+#endif
 #ifdef LZF_SEG_TIME
                     ++n_rounds;
 #endif
                     const unsigned long long mA = ml & mA_b, m2 = ml & m2_b, m3 = ml & m3_b, m4 = ml & m4_b, mS = ml & mS_b;
                     RT(tm_setup);
+#if defined(LZF_SEG_DBG_SKIP) && LZF_SEG_DBG_SKIP == 1      // analysis: the level loop without its copies (what the control around a round costs)
+                    continue;
+#endif
                     if (mA | m2) {
                         uint64_t v0, v1, v2, v3, v4, v5, v6, v7; uint32_t va0, va1; unsigned long long sv;
                         asm volatile(
@@ -1010,26 +1103,40 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                     if (mS) {
                         const bool nowS = (mS >> lane) & 1ull;
                         const bool fits = nowS && (((dy - off) & kMask) + M <= (uint32_t)R) && ((dy & kMask) + M <= (uint32_t)R);   // neither range wraps
-                        // (a) run-length matches (offset 1, 2 or 4), any length up to 512: the pattern from one read, stores only
-                        const bool rle = fits && (off == 1u || off == 2u || off == 4u) && M <= 512u;
-                        if (rle) {
-                            uint32_t w; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(sa) : "memory");
-                            if (off == 1u) w = (w & 0xFFu) * 0x01010101u; else if (off == 2u) w = (w & 0xFFFFu) * 0x00010001u;
-                            const uint64_t pat = (uint64_t)w | ((uint64_t)w << 32);
-                            if (M >= 8u) {
-                                for (uint32_t k = 0; k + 8u < M; k += 8u) lds_st64(da + k, pat);
-                                // the last piece ends exactly at M: its phase is (M - 8) mod off; off divides 8 and M - 8 - k0 ... rotate by bytes
-                                const uint32_t ph = (M - 8u) & (off - 1u);
-                                const uint64_t rot = ph ? (pat >> (8u * ph)) | (pat << (64u - 8u * ph)) : pat;
-                                lds_st64(da + M - 8u, rot);
-                            } else {
-                                lds_st32(da, w);
-                                const uint32_t ph = (M - 4u) & (off - 1u);
-                                lds_st32(da + M - 4u, ph ? (uint32_t)(pat >> (8u * ph)) : w);
+                        // (a) run-length matches (offset 1, 2 or 4): the pattern from one read, stores only.  Up to 64 bytes in
+                        // the lane; longer ones by the whole wave, one after the other (512 bytes a step), the lane's own
+                        // store finishing the odd end
+                        const bool rle = fits && (off == 1u || off == 2u || off == 4u);
+                        if (__ballot(rle)) {
+                            uint32_t w = 0;
+                            if (rle) {
+                                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(sa) : "memory");
+                                if (off == 1u) w = (w & 0xFFu) * 0x01010101u; else if (off == 2u) w = (w & 0xFFFFu) * 0x00010001u;
+                                const uint64_t pat = (uint64_t)w | ((uint64_t)w << 32);
+                                if (M >= 8u) {
+                                    if (M <= 64u) for (uint32_t k = 0; k + 8u < M; k += 8u) lds_st64(da + k, pat);
+                                    // the last piece ends exactly at M: its phase is (M - 8) mod off (off divides 8): rotate by bytes
+                                    const uint32_t ph = (M - 8u) & (off - 1u);
+                                    const uint64_t rot = ph ? (pat >> (8u * ph)) | (pat << (64u - 8u * ph)) : pat;
+                                    lds_st64(da + M - 8u, rot);
+                                } else {
+                                    lds_st32(da, w);
+                                    const uint32_t ph = (M - 4u) & (off - 1u);
+                                    lds_st32(da + M - 4u, ph ? (uint32_t)(pat >> (8u * ph)) : w);
+                                }
+                            }
+                            for (unsigned long long m = __ballot(rle && M > 64u); m; m &= m - 1ull) {
+                                const uint32_t q = (uint32_t)__builtin_ctzll(m);
+                                const uint32_t qd = __builtin_amdgcn_readlane(da, q), qM = __builtin_amdgcn_readlane(M, q);
+                                const uint32_t qw = __builtin_amdgcn_readlane(w, q);
+                                const uint64_t qp = (uint64_t)qw | ((uint64_t)qw << 32);
+                                for (uint32_t k = 8u * lane; k + 8u <= qM; k += 8u * kWave) lds_st64(qd + k, qp);
                             }
                         }
-                        // (b) not overlapping, 65..160 bytes: 32 bytes per step, the last step two-ended
-                        const bool lng = fits && !rle && off >= M && M <= 160u;
+                        // (b) not overlapping, 65..160 bytes, four or more of them in the level: 32 bytes per step in the lane,
+                        // the last step two-ended (fewer: the whole wave is quicker, (d))
+                        const bool lngc = fits && !rle && off >= M && M <= 160u;
+                        const bool lng = lngc && __builtin_popcountll(__ballot(lngc)) >= 4;
                         if (lng) {
                             uint32_t k = 0;
                             for (;;) {
@@ -1060,7 +1167,7 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
             if (gave_up) break;
         }
 #ifdef LZF_SEG_TIME
-        if (lane == 0u) { c.st[j].pad = n_rounds;
+        if (lane == 0u) { reinterpret_cast<uint16_t*>(&c.st[j].pad)[0] = (uint16_t)(n_rounds >> 4);
             c.st[j].pad2 = (unsigned long long)(uint16_t)(tm_wait >> 14) | ((unsigned long long)(uint16_t)(tm_setup >> 14) << 16) | ((unsigned long long)(uint16_t)(tm_asm >> 14) << 32) | ((unsigned long long)(uint16_t)(tm_slow >> 14) << 48); }
 #endif
 #undef RT
@@ -1085,6 +1192,26 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
             for (uint32_t y = fp + 16u * lane; y < g1; y += 16u * kWave)
                 *reinterpret_cast<u32x4*>(&ring[y & kMask]) = *reinterpret_cast<const LZF_GLOBAL u32x4*>(outb + y);
             if (g1 > fp) fp = g1;
+        };
+        // the granules behind the fill pointer, loaded one sub-batch early (the load's latency runs under the hand-over)
+        u32x4 pfa = u32x4{0, 0, 0, 0}, pfb = u32x4{0, 0, 0, 0};
+        uint32_t pf0 = 0, pf1 = 0;                       // [pf0, pf1) is held in registers
+        const uint32_t fill_lim = (total + rb + 15u) & ~15u;
+        auto prefetch_issue = [&](uint32_t need) {       // (the fill pointer stays within 3 KiB of what the sub-batch needed: the levels' fetch-ahead bound)
+            pf0 = fp; pf1 = fp + 2048u < fill_lim ? fp + 2048u : fill_lim;
+            if (pf1 <= pf0 || fp > need + 1024u) { pf0 = pf1 = 0; return; }
+            const uint32_t ya = pf0 + 16u * lane, yb = ya + 1024u;
+            if (ya < pf1) pfa = *reinterpret_cast<const LZF_GLOBAL u32x4*>(outb + ya);
+            if (yb < pf1) pfb = *reinterpret_cast<const LZF_GLOBAL u32x4*>(outb + yb);
+        };
+        auto prefetch_commit = [&]() {
+            if (pf1 > pf0 && pf0 == fp) {
+                const uint32_t ya = pf0 + 16u * lane, yb = ya + 1024u;
+                if (ya < pf1) *reinterpret_cast<u32x4*>(&ring[ya & kMask]) = pfa;
+                if (yb < pf1) *reinterpret_cast<u32x4*>(&ring[yb & kMask]) = pfb;
+                fp = pf1;
+            }
+            pf0 = pf1 = 0;
         };
         // write what the resolver has finished to HBM (whole granules), in ticket order
         auto flush_resolved = [&](uint32_t upto_t) {
@@ -1132,6 +1259,7 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                     const uint32_t g_dy = __builtin_amdgcn_readlane(dy, gl), g_M = __builtin_amdgcn_readlane(M, gl), g_off = __builtin_amdgcn_readlane(off, gl);
                     wait_resolved(ticket);
                     flush_resolved(ticket);
+                    pf0 = pf1 = 0;                        // (what was loaded early may lie under the copy)
                     if (fp < ((prev_end + 15u) & ~15u)) fill_to((prev_end + 15u) & ~15u);
                     flush_range(fl, prev_end); if (prev_end > fl) fl = prev_end;
                     wave_store_fence();
@@ -1158,8 +1286,20 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                 } else {
                     // ---- sub-batch: the ring filled, the sources older than the ring moved in
                     if (ticket >= NS) wait_resolved(ticket - NS + 1u);
+#if defined(LZF_SEG_DBG_SKIP) && LZF_SEG_DBG_SKIP == 3      // analysis: a stager that moves no bytes (what the resolver costs on its own)
+                    if (false)
+#endif
                     { const uint32_t rs = flag_get(1); flush_resolved(rs < ticket ? rs : ticket); }
+#if defined(LZF_SEG_DBG_SKIP) && LZF_SEG_DBG_SKIP == 3
+                    fp = (oe + 15u) & ~15u;
+#endif
+#ifndef LZF_SEG_NOPF
+                    prefetch_commit();
+#endif
                     fill_to((oe + 15u) & ~15u);
+#ifndef LZF_SEG_NOPF
+                    prefetch_issue((oe + 15u) & ~15u);
+#endif
                     const bool old = sub == s_i && cls == 7u;
                     if (__ballot(old)) {
                         const uint32_t span = M < off ? M : off;
@@ -1184,17 +1324,25 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                 }
                 const uint32_t eg = oe & ~15u;
                 { const uint32_t k3 = ticket % 3u; if (k3 == 0u) endq0 = eg; else if (k3 == 1u) endq1 = eg; else endq2 = eg; }
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifdef LZF_SEG_VMW
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ring and the slot written; loads and stores to HBM stay in flight
                 ++ticket;
                 if (lane == 0u) flag_set(0, ticket);
                 prev_end = oe;
             }
         }
         wait_resolved(ticket);
+#if !(defined(LZF_SEG_DBG_SKIP) && LZF_SEG_DBG_SKIP == 3)
         flush_resolved(ticket);
         flush_range(fl, total + rb);
+#endif
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 
+#ifdef LZF_SEG_TIME
+        if (lane == 0u) reinterpret_cast<uint16_t*>(&c.st[j].pad)[1] = (uint16_t)(tm_swait >> 14);
+#endif
         if (lane == 0u) {
             c.results[j].out_len = total;
             c.results[j].status = LZF_OK;

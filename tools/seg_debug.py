@@ -212,7 +212,8 @@ def run(blocks, min_in, upto, verbose=True):
             extra = ""
             if int(s["pad"]):
                 p2 = int(s["pad2"])
-                extra = f", rounds {int(s['pad'])} ({int(s['pad']) / max(1, (len(toks) + 63) // 64):.2f}/batch), resolver kcycles: wait {(p2 & 0xFFFF) << 4} setup {((p2 >> 16) & 0xFFFF) << 4} asm rounds {((p2 >> 32) & 0xFFFF) << 4} slow paths {((p2 >> 48) & 0xFFFF) << 4}"
+                nr = (int(s['pad']) & 0xFFFF) << 4
+                extra = f", rounds {nr} ({nr / max(1, (len(toks) + 63) // 64):.2f}/batch), stager waiting {(int(s['pad']) >> 16) << 4} kcycles, resolver kcycles: wait {(p2 & 0xFFFF) << 4} setup {((p2 >> 16) & 0xFFFF) << 4} asm rounds {((p2 >> 32) & 0xFFFF) << 4} slow paths {((p2 >> 48) & 0xFFFF) << 4}"
             print(f"  [{name}] ok (comp {len(cdat)}, {len(toks)} tokens, failed={s['failed']}, kcycles {res[i]['reserved']}{extra})")
     return ok_all
 
