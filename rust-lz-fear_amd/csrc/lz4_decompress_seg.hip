@@ -825,7 +825,7 @@ __global__ __launch_bounds__(64) void lzf_seg_records_kernel(seg_ctx c) {
                         const bool wrap = di + M > R || si + M > R;
                         if (sy < lov) cls = 7u;
                         else if (M > 64u || wrap) cls = 6u;
-                        else if (off < M) cls = 5u;
+                        else if (off < M) cls = (off == 1u || off == 2u || off == 4u) ? (M < 8u ? 9u : M <= 16u ? 10u : M <= 32u ? 11u : 12u) : 5u;
                         else cls = M < 8u ? 1u : M <= 16u ? 2u : M <= 32u ? 3u : 4u;
                     }
                 }
@@ -941,8 +941,22 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
             // two-ended pieces: A (4..7) = 4-byte pieces at 0 and M - 4; B1 (8..16) = 8-byte pieces at 0 and M - 8;
             // B2 (17..32) adds 8 and M - 16; C (33..64) adds 16, 24, M - 32, M - 24
             const uint32_t o3 = M - 8u, a1 = M - 4u;
+#if !defined(LZF_SEG_NOASM) && !defined(LZF_SEG_DBG_SKIP) && !defined(LZF_SEG_NORLE)
+            // classes 9..12: run-length matches (offset 1, 2 or 4) of the same four sizes — stored like 1..4, the registers filled
+            // with the pattern (the first bytes read, spread by v_perm_b32; rotated for the piece that ends the match)
+            const unsigned long long mR_b = __ballot(cls >= 9u && cls <= 12u);
+            const unsigned long long mA_b = __ballot(cls == 1u || cls == 9u), m2_b = __ballot((cls >= 2u && cls <= 4u) || (cls >= 10u && cls <= 12u)),
+                                     m3_b = __ballot(cls == 3u || cls == 4u || cls == 11u || cls == 12u),
+                                     m4_b = __ballot(cls == 4u || cls == 12u), mS_b = __ballot(cls == 5u || cls == 6u);
+            const uint32_t rsel = off == 1u ? 0u : off == 2u ? 0x01000100u : 0x03020100u, rsh = M & (off - 1u);
+#else
+            // (the compiler's loop: the run-length classes take the general path (a) below)
             const unsigned long long mA_b = __ballot(cls == 1u), m2_b = __ballot(cls >= 2u && cls <= 4u), m3_b = __ballot(cls == 3u || cls == 4u),
-                                     m4_b = __ballot(cls == 4u), mS_b = __ballot(cls == 5u || cls == 6u);
+                                     m4_b = __ballot(cls == 4u), mS_b = __ballot(cls == 5u || cls == 6u || (cls >= 9u && cls <= 12u));
+#ifdef LZF_SEG_NORLE
+            const unsigned long long mR_b = 0; const uint32_t rsel = 0, rsh = 0;
+#endif
+#endif
             bool gave_up = false;
             for (uint32_t s_i = 0; s_i < nsub; ++s_i, ++t) {
                 // ---- wait for the stager's ticket
@@ -959,12 +973,14 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                 for (uint32_t lv = 1; todo; ++lv) {
                     unsigned long long ml;
 #if !defined(LZF_SEG_NOASM) && !defined(LZF_SEG_DBG_SKIP)
-                    // The levels whose sequences are all of the two-ended classes, in one hand-scheduled loop: a lone wavefront
-                    // retires an instruction every 5 to 8 cycles, so the round is priced by its instruction count (18 scalar
-                    // instructions + the DS pairs of the classes present; what hipcc makes of the loop below is 45 + 8 EXEC moves).
-                    // It hands a level with a lane of class 5/6 (already taken out of `todo`, in `ml`) to the code below.
+                    // The rounds of the two-ended classes in one hand-scheduled loop: a lone wavefront retires an instruction every
+                    // 5 to 8 cycles, so a round is priced by its instruction count (about 20 scalar instructions + the DS pairs of
+                    // the classes present; what hipcc makes of the loop below is 45 + 8 EXEC moves).  It returns after a level
+                    // that has lanes of class 5/6 (`ts`; the level's other lanes done) for the code below.  v100..v117: the
+                    // pieces in flight, fixed registers so that the halves of a pair can be named.
+                    unsigned long long ts;
                     {
-                        uint64_t v0, v1, v2, v3, v4, v5, v6, v7; uint32_t va0, va1; unsigned long long sv, ts;
+                        unsigned long long sv;
                         lv = __builtin_amdgcn_readfirstlane(lv);
                         asm volatile(
                             "s_mov_b64 %[sv], exec\n\t"
@@ -974,81 +990,101 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                             "s_and_b64 %[ml], vcc, %[todo]\n\t"
                             "s_cbranch_scc0 Lempty%=\n\t"
                             "s_andn2_b64 %[todo], %[todo], %[ml]\n\t"
-                            "s_and_b64 %[ts], %[ml], %[mS]\n\t"
-                            "s_cbranch_scc1 Lout%=\n\t"
 #ifdef LZF_SEG_TIME
                             "s_add_u32 %[nr], %[nr], 1\n\t"
 #endif
                             "s_and_b64 exec, %[ml], %[mA]\n\t"
-                            "ds_read_b32 %[va0], %[sa]\n\t"
-                            "ds_read_b32 %[va1], %[s1]\n\t"
+                            "ds_read_b32 v116, %[sa]\n\t"
+                            "ds_read_b32 v117, %[s1]\n\t"
                             "s_and_b64 exec, %[ml], %[m2]\n\t"
-                            "ds_read_b64 %[v0], %[sa]\n\t"
-                            "ds_read_b64 %[v3], %[s3]\n\t"
+                            "ds_read_b64 v[100:101], %[sa]\n\t"
+                            "ds_read_b64 v[106:107], %[s3]\n\t"
                             "s_and_b64 exec, %[ml], %[m3]\n\t"
                             "s_cbranch_execz Lr%=\n\t"
-                            "ds_read_b64 %[v1], %[sa] offset:8\n\t"
-                            "ds_read_b64 %[v2], %[s16]\n\t"
+                            "ds_read_b64 v[102:103], %[sa] offset:8\n\t"
+                            "ds_read_b64 v[104:105], %[s16]\n\t"
                             "s_and_b64 exec, %[ml], %[m4]\n\t"
                             "s_cbranch_execz Lr%=\n\t"
-                            "ds_read_b64 %[v4], %[sa] offset:16\n\t"
-                            "ds_read_b64 %[v5], %[sa] offset:24\n\t"
-                            "ds_read_b64 %[v6], %[s32]\n\t"
-                            "ds_read_b64 %[v7], %[s32] offset:8\n\t"
+                            "ds_read_b64 v[108:109], %[sa] offset:16\n\t"
+                            "ds_read_b64 v[110:111], %[sa] offset:24\n\t"
+                            "ds_read_b64 v[112:113], %[s32]\n\t"
+                            "ds_read_b64 v[114:115], %[s32] offset:8\n\t"
                             "Lr%=:\n\t"
+                            "s_and_b64 exec, %[ml], %[mR]\n\t"
                             "s_waitcnt lgkmcnt(0)\n\t"
+                            "s_cbranch_execz Lnr%=\n\t"
+                            // run-length lanes: the pattern (what was read at the source, spread over the word) in every piece
+                            // from the front, the pattern rotated by M mod offset in every piece that ends with the match
+                            "v_perm_b32 v116, v116, v116, %[rsel]\n\t"
+                            "v_perm_b32 v100, v100, v100, %[rsel]\n\t"
+                            "v_alignbyte_b32 v117, v116, v116, %[rsh]\n\t"
+                            "v_alignbyte_b32 v106, v100, v100, %[rsh]\n\t"
+                            "v_mov_b32 v101, v100\n\t"
+                            "v_mov_b32 v107, v106\n\t"
+                            "v_mov_b64 v[102:103], v[100:101]\n\t"
+                            "v_mov_b64 v[104:105], v[106:107]\n\t"
+                            "v_mov_b64 v[108:109], v[100:101]\n\t"
+                            "v_mov_b64 v[110:111], v[100:101]\n\t"
+                            "v_mov_b64 v[112:113], v[106:107]\n\t"
+                            "v_mov_b64 v[114:115], v[106:107]\n\t"
+                            "Lnr%=:\n\t"
                             "s_and_b64 exec, %[ml], %[mA]\n\t"
-                            "ds_write_b32 %[da], %[va0]\n\t"
-                            "ds_write_b32 %[d1], %[va1]\n\t"
+                            "ds_write_b32 %[da], v116\n\t"
+                            "ds_write_b32 %[d1], v117\n\t"
                             "s_and_b64 exec, %[ml], %[m2]\n\t"
-                            "ds_write_b64 %[da], %[v0]\n\t"
-                            "ds_write_b64 %[d3], %[v3]\n\t"
+                            "ds_write_b64 %[da], v[100:101]\n\t"
+                            "ds_write_b64 %[d3], v[106:107]\n\t"
                             "s_and_b64 exec, %[ml], %[m3]\n\t"
                             "s_cbranch_execz Lw%=\n\t"
-                            "ds_write_b64 %[da], %[v1] offset:8\n\t"
-                            "ds_write_b64 %[d16], %[v2]\n\t"
+                            "ds_write_b64 %[da], v[102:103] offset:8\n\t"
+                            "ds_write_b64 %[d16], v[104:105]\n\t"
                             "s_and_b64 exec, %[ml], %[m4]\n\t"
                             "s_cbranch_execz Lw%=\n\t"
-                            "ds_write_b64 %[da], %[v4] offset:16\n\t"
-                            "ds_write_b64 %[da], %[v5] offset:24\n\t"
-                            "ds_write_b64 %[d32], %[v6]\n\t"
-                            "ds_write_b64 %[d32], %[v7] offset:8\n\t"
+                            "ds_write_b64 %[da], v[108:109] offset:16\n\t"
+                            "ds_write_b64 %[da], v[110:111] offset:24\n\t"
+                            "ds_write_b64 %[d32], v[112:113]\n\t"
+                            "ds_write_b64 %[d32], v[114:115] offset:8\n\t"
                             "Lw%=:\n\t"
                             "s_mov_b64 exec, %[sv]\n\t"
+                            "s_and_b64 %[ts], %[ml], %[mS]\n\t"
+                            "s_cbranch_scc1 Lout%=\n\t"
                             "s_cmp_lg_u64 %[todo], 0\n\t"
                             "s_cbranch_scc1 Lloop%=\n\t"
-                            "s_mov_b64 %[ts], 0\n\t"
                             "s_branch Lout%=\n\t"
                             "Lempty%=:\n\t"
+                            "s_mov_b64 %[ts], 0\n\t"
                             "s_cmp_le_u32 %[lv], 71\n\t"
                             "s_cbranch_scc1 Lloop%=\n\t"
-                            "s_mov_b64 %[ts], 0\n\t"
                             "Lout%=:\n\t"
-                            : [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3), [v4] "=&v"(v4), [v5] "=&v"(v5), [v6] "=&v"(v6), [v7] "=&v"(v7),
-                              [va0] "=&v"(va0), [va1] "=&v"(va1), [sv] "=&s"(sv), [ts] "=&s"(ts), [ml] "=&s"(ml), [todo] "+s"(todo), [lv] "+s"(lv)
+                            : [sv] "=&s"(sv), [ts] "=&s"(ts), [ml] "=&s"(ml), [todo] "+s"(todo), [lv] "+s"(lv)
 #ifdef LZF_SEG_TIME
                               , [nr] "+s"(n_rounds)
 #endif
-                            : [mA] "s"(mA_b), [m2] "s"(m2_b), [m3] "s"(m3_b), [m4] "s"(m4_b), [mS] "s"(mS_b), [vl] "v"(lvl),
+                            : [mA] "s"(mA_b), [m2] "s"(m2_b), [m3] "s"(m3_b), [m4] "s"(m4_b), [mS] "s"(mS_b), [mR] "s"(mR_b), [vl] "v"(lvl), [rsel] "v"(rsel), [rsh] "v"(rsh),
                               [sa] "v"(sa), [s1] "v"(sa + a1), [s3] "v"(sa + o3), [s16] "v"(sa + M - 16u), [s32] "v"(sa + M - 32u),
                               [da] "v"(da), [d1] "v"(da + a1), [d3] "v"(da + o3), [d16] "v"(da + M - 16u), [d32] "v"(da + M - 32u)
-                            : "memory", "vcc", "scc");
+                            : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113",
+                              "v114", "v115", "v116", "v117");
                         RT(tm_asm);
                         // (hipcc takes what an asm statement returns for divergent, whatever the register class)
-                        auto uni = [](unsigned long long x) { return (unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)x) | ((unsigned long long)__builtin_amdgcn_readfirstlane((uint32_t)(x >> 32)) << 32); };
+                        auto uni = [](unsigned long long x) { return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)x) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x >> 32)) << 32); };
                         ts = uni(ts); ml = uni(ml); todo = uni(todo); lv = __builtin_amdgcn_readfirstlane(lv);
                         if (!ts) break;                  // nothing left (or levels that do not end: not our records)
-                        --lv;                            // (the level in `ml`; the loop's increment follows)
+                        --lv;                            // (the loop's increment follows)
                     }
 #else
                     ml = __ballot(lvl == lv) & todo;
                     if (!ml) { if (lv > 70u) break; continue; }
                     todo &= ~ml;
 #endif
+#if !defined(LZF_SEG_NOASM) && !defined(LZF_SEG_DBG_SKIP)
+                    const unsigned long long mA = 0, m2 = 0, m3 = 0, m4 = 0, mS = ts;
+#else
 #ifdef LZF_SEG_TIME
                     ++n_rounds;
 #endif
                     const unsigned long long mA = ml & mA_b, m2 = ml & m2_b, m3 = ml & m3_b, m4 = ml & m4_b, mS = ml & mS_b;
+#endif
                     RT(tm_setup);
 #if defined(LZF_SEG_DBG_SKIP) && LZF_SEG_DBG_SKIP == 1      // analysis: the level loop without its copies (what the control around a round costs)
                     continue;

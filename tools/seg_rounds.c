@@ -29,13 +29,13 @@ int main(int argc, char** argv) {
     uint8_t* data = malloc(total); if (fread(data, 1, total, f) != total) return 1; fclose(f);
     uint8_t* comp = malloc(BS + 65536); seqs = malloc(sizeof(seq_t) * (BS / 2));
     uint8_t* lev = malloc(BS + 16);
-    printf("blk   nseq batches rounds | rounds with: only-fast  any-slow | slow lanes: rle lng dbl wave | wave lanes per round 1 2 3-4 5-8 >8 | wave bytes  mean M | lng+wave per round hist 1 2 3-4 5-8 >8\n");
+    printf("blk   nseq batches rounds | rounds with: only-fast  any-slow | slow lanes: rle lng dbl wave | wave lanes per round 1 2 3-4 5-8 >8 | wave bytes  mean M | lng+wave per round hist 1 2 3-4 5-8 >8 | rle lanes by M: 4-7 8-16 17-32 33-64 >64\n");
     for (size_t b0 = 0, bi = 0; b0 < total; b0 += BS, ++bi) {
         size_t n = total - b0 < BS ? total - b0 : BS, clen = 0;
         lzfo_u32_table t; memset(&t, 0, sizeof t);
         if (lzfo_compress2(data + b0, n, 0, LZFO_TABLE_U32, &t, comp, n, &clen) != LZFO_OK) { printf("%zu stored\n", bi); continue; }
         parse(comp, clen);
-        unsigned long rounds = 0, fastonly = 0, anyslow = 0, n_rle = 0, n_lng = 0, n_dbl = 0, n_wave = 0, wbytes = 0, wh[5] = {0}, lh[5] = {0};
+        unsigned long rh[5] = {0}, rounds = 0, fastonly = 0, anyslow = 0, n_rle = 0, n_lng = 0, n_dbl = 0, n_wave = 0, wbytes = 0, wh[5] = {0}, lh[5] = {0};
         for (size_t i0 = 0; i0 < nseq; i0 += 64) {
             size_t i1 = i0 + 64 < nseq ? i0 + 64 : nseq; uint32_t ts = seqs[i0].lo; int lv[64], mx = 0;
             for (size_t j = i0; j < i1; ++j) {
@@ -52,7 +52,7 @@ int main(int argc, char** argv) {
                 for (size_t j = i0; j < i1; ++j) if (lv[j - i0] == l) {
                     seq_t* s = &seqs[j];
                     if (s->M <= 64 && s->off >= s->M) ++fast;
-                    else if ((s->off == 1 || s->off == 2 || s->off == 4) && s->M <= 512) ++rle;
+                    else if (s->off == 1 || s->off == 2 || s->off == 4) { ++rle; ++rh[s->M < 8 ? 0 : s->M <= 16 ? 1 : s->M <= 32 ? 2 : s->M <= 64 ? 3 : 4]; }
                     else if (s->off >= s->M && s->M <= 160) ++lng;
                     else if (s->M <= 64) ++dbl;
                     else { ++wave; wbytes += s->M; }
@@ -63,8 +63,8 @@ int main(int argc, char** argv) {
                 int lw = lng + wave; if (lw) ++lh[lw == 1 ? 0 : lw == 2 ? 1 : lw <= 4 ? 2 : lw <= 8 ? 3 : 4];
             }
         }
-        printf("%2zu %7zu %6zu %6lu | %6lu %6lu | %6lu %6lu %6lu %6lu | %5lu %5lu %5lu %5lu %5lu | %8lu %6.0f | %5lu %5lu %5lu %5lu %5lu\n", bi, nseq, (nseq + 63) / 64, rounds, fastonly, anyslow,
-               n_rle, n_lng, n_dbl, n_wave, wh[0], wh[1], wh[2], wh[3], wh[4], wbytes, n_wave ? (double)wbytes / n_wave : 0.0, lh[0], lh[1], lh[2], lh[3], lh[4]);
+        printf("%2zu %7zu %6zu %6lu | %6lu %6lu | %6lu %6lu %6lu %6lu | %5lu %5lu %5lu %5lu %5lu | %8lu %6.0f | %5lu %5lu %5lu %5lu %5lu | rle M: %lu %lu %lu %lu %lu\n", bi, nseq, (nseq + 63) / 64, rounds, fastonly, anyslow,
+               n_rle, n_lng, n_dbl, n_wave, wh[0], wh[1], wh[2], wh[3], wh[4], wbytes, n_wave ? (double)wbytes / n_wave : 0.0, lh[0], lh[1], lh[2], lh[3], lh[4], rh[0], rh[1], rh[2], rh[3], rh[4]);
     }
     return 0;
 }
