@@ -863,8 +863,6 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
     constexpr uint32_t NS = 3;                         // tickets the stager may be ahead
     __shared__ __attribute__((aligned(16))) uint8_t ring[R];
     __shared__ uint32_t ctl[4];                        // [0] staged tickets, [1] resolved tickets
-    constexpr uint32_t NB = 4;                         // batches of records the stager keeps in LDS for the resolver (> NS)
-    __shared__ __attribute__((aligned(16))) u32x4 rslots[NB][64];
     const uint32_t j = blockIdx.x;
     if (j >= c.n_jobs) return;
     const seg_job sj = c.st[j];
@@ -926,14 +924,29 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
 #else
 #define RT(var) do { } while (0)
 #endif
-        uint32_t t = 0;
+        uint32_t t = 0, staged = 0;                       // tickets resolved; tickets known to be staged (the flag as last read)
+        // the records come straight from HBM, two batches ahead (the only loads of this wave: they return in order and in time)
+        u32x4 rA = u32x4{0, 0, 0, 0}, rB = u32x4{0, 0, 0, 0};
+        if (n) { rA = recs[lane < n ? lane : n - 1u]; rB = recs[64u + lane < n ? 64u + lane : n - 1u]; }
+        auto wait_staged = [&](uint32_t tt) -> bool {    // ticket tt published?  (one read of the flag usually covers several tickets)
+            if (staged > tt) return true;
+            for (uint32_t spin = 0;; ++spin) {
+                staged = flag_get(0);
+                if (staged > tt) return true;
+                if ((spin & 63u) == 63u && (flag_get(3) != 0u || spin > (1u << 22))) { if (lane == 0u) flag_set(3, 1u); return false; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        };
         for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
             const uint32_t nb = n - i0 < 64u ? n - i0 : 64u;
-            // the batch's records are in their slot once its first ticket is published
+            const u32x4 r = rA;
+            asm volatile("" ::: "memory");
+            rA = rB;
+            { const uint32_t ix = i0 + 128u + lane; rB = recs[ix < n ? ix : n - 1u]; }
+            asm volatile("" ::: "memory");
             RT(tm_setup);
-            if (!flag_wait_above(0, t)) break;
+            if (!wait_staged(t)) break;
             RT(tm_wait);
-            const u32x4 r = rslots[(i0 >> 6) % NB][lane];
             const uint32_t M = r[0], dy = r[1], off = r[3];
             const uint32_t sub = lane < nb ? (r[2] & 0xFFu) : 0xFFu, lvl = (r[2] >> 16) & 255u, cls = lane < nb ? r[2] >> 24 : 0u;
             const uint32_t nsub = __builtin_amdgcn_readlane(r[2] & 0xFFu, (nb - 1u) & 63u) + 1u;
@@ -962,7 +975,7 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                 // ---- wait for the stager's ticket
                 if (s_i) {
                     RT(tm_setup);
-                    if (!flag_wait_above(0, t)) { gave_up = true; break; }
+                    if (!wait_staged(t)) { gave_up = true; break; }
                     RT(tm_wait);
                 }
                 const unsigned long long msub = nsub == 1u ? ~0ull : __ballot(sub == s_i);
@@ -982,6 +995,8 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                     {
                         unsigned long long sv;
                         lv = __builtin_amdgcn_readfirstlane(lv);
+                        // (two copies: batches without run-length and class-5/6 lanes — most of a text block's — skip those checks)
+                        if ((mR_b | mS_b) & msub)
                         asm volatile(
                             "s_mov_b64 %[sv], exec\n\t"
                             "Lloop%=:\n\t"
@@ -989,7 +1004,6 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                             "s_add_u32 %[lv], %[lv], 1\n\t"
                             "s_and_b64 %[ml], vcc, %[todo]\n\t"
                             "s_cbranch_scc0 Lempty%=\n\t"
-                            "s_andn2_b64 %[todo], %[todo], %[ml]\n\t"
 #ifdef LZF_SEG_TIME
                             "s_add_u32 %[nr], %[nr], 1\n\t"
 #endif
@@ -1011,7 +1025,9 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                             "ds_read_b64 v[114:115], %[s32] offset:8\n\t"
                             "Lr%=:\n\t"
                             "s_and_b64 exec, %[ml], %[mR]\n\t"
+#ifndef LZF_SEG_DBG_NOWAIT                                         // (analysis: the round without its LDS latency; wrong bytes)
                             "s_waitcnt lgkmcnt(0)\n\t"
+#endif
                             "s_cbranch_execz Lnr%=\n\t"
                             // run-length lanes: the pattern (what was read at the source, spread over the word) in every piece
                             // from the front, the pattern rotated by M mod offset in every piece that ends with the match
@@ -1048,7 +1064,72 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                             "s_mov_b64 exec, %[sv]\n\t"
                             "s_and_b64 %[ts], %[ml], %[mS]\n\t"
                             "s_cbranch_scc1 Lout%=\n\t"
-                            "s_cmp_lg_u64 %[todo], 0\n\t"
+                            "s_andn2_b64 %[todo], %[todo], %[ml]\n\t"
+                            "s_cbranch_scc1 Lloop%=\n\t"
+                            "s_branch Lout%=\n\t"
+                            "Lempty%=:\n\t"
+                            "s_mov_b64 %[ts], 0\n\t"
+                            "s_cmp_le_u32 %[lv], 71\n\t"
+                            "s_cbranch_scc1 Lloop%=\n\t"
+                            "Lout%=:\n\t"
+                            : [sv] "=&s"(sv), [ts] "=&s"(ts), [ml] "=&s"(ml), [todo] "+s"(todo), [lv] "+s"(lv)
+#ifdef LZF_SEG_TIME
+                              , [nr] "+s"(n_rounds)
+#endif
+                            : [mA] "s"(mA_b), [m2] "s"(m2_b), [m3] "s"(m3_b), [m4] "s"(m4_b), [mS] "s"(mS_b), [mR] "s"(mR_b), [vl] "v"(lvl), [rsel] "v"(rsel), [rsh] "v"(rsh),
+                              [sa] "v"(sa), [s1] "v"(sa + a1), [s3] "v"(sa + o3), [s16] "v"(sa + M - 16u), [s32] "v"(sa + M - 32u),
+                              [da] "v"(da), [d1] "v"(da + a1), [d3] "v"(da + o3), [d16] "v"(da + M - 16u), [d32] "v"(da + M - 32u)
+                            : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113",
+                              "v114", "v115", "v116", "v117");
+                        else
+                        asm volatile(
+                            "s_mov_b64 %[sv], exec\n\t"
+                            "s_mov_b64 %[ts], 0\n\t"
+                            "Lloop%=:\n\t"
+                            "v_cmp_eq_u32_e32 vcc, %[lv], %[vl]\n\t"
+                            "s_add_u32 %[lv], %[lv], 1\n\t"
+                            "s_and_b64 %[ml], vcc, %[todo]\n\t"
+                            "s_cbranch_scc0 Lempty%=\n\t"
+#ifdef LZF_SEG_TIME
+                            "s_add_u32 %[nr], %[nr], 1\n\t"
+#endif
+                            "s_and_b64 exec, %[ml], %[mA]\n\t"
+                            "ds_read_b32 v116, %[sa]\n\t"
+                            "ds_read_b32 v117, %[s1]\n\t"
+                            "s_and_b64 exec, %[ml], %[m2]\n\t"
+                            "ds_read_b64 v[100:101], %[sa]\n\t"
+                            "ds_read_b64 v[106:107], %[s3]\n\t"
+                            "s_and_b64 exec, %[ml], %[m3]\n\t"
+                            "s_cbranch_execz Lr%=\n\t"
+                            "ds_read_b64 v[102:103], %[sa] offset:8\n\t"
+                            "ds_read_b64 v[104:105], %[s16]\n\t"
+                            "s_and_b64 exec, %[ml], %[m4]\n\t"
+                            "s_cbranch_execz Lr%=\n\t"
+                            "ds_read_b64 v[108:109], %[sa] offset:16\n\t"
+                            "ds_read_b64 v[110:111], %[sa] offset:24\n\t"
+                            "ds_read_b64 v[112:113], %[s32]\n\t"
+                            "ds_read_b64 v[114:115], %[s32] offset:8\n\t"
+                            "Lr%=:\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "s_and_b64 exec, %[ml], %[mA]\n\t"
+                            "ds_write_b32 %[da], v116\n\t"
+                            "ds_write_b32 %[d1], v117\n\t"
+                            "s_and_b64 exec, %[ml], %[m2]\n\t"
+                            "ds_write_b64 %[da], v[100:101]\n\t"
+                            "ds_write_b64 %[d3], v[106:107]\n\t"
+                            "s_and_b64 exec, %[ml], %[m3]\n\t"
+                            "s_cbranch_execz Lw%=\n\t"
+                            "ds_write_b64 %[da], v[102:103] offset:8\n\t"
+                            "ds_write_b64 %[d16], v[104:105]\n\t"
+                            "s_and_b64 exec, %[ml], %[m4]\n\t"
+                            "s_cbranch_execz Lw%=\n\t"
+                            "ds_write_b64 %[da], v[108:109] offset:16\n\t"
+                            "ds_write_b64 %[da], v[110:111] offset:24\n\t"
+                            "ds_write_b64 %[d32], v[112:113]\n\t"
+                            "ds_write_b64 %[d32], v[114:115] offset:8\n\t"
+                            "Lw%=:\n\t"
+                            "s_mov_b64 exec, %[sv]\n\t"
+                            "s_andn2_b64 %[todo], %[todo], %[ml]\n\t"
                             "s_cbranch_scc1 Lloop%=\n\t"
                             "s_branch Lout%=\n\t"
                             "Lempty%=:\n\t"
@@ -1070,6 +1151,7 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                         auto uni = [](unsigned long long x) { return (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)x) | ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(x >> 32)) << 32); };
                         ts = uni(ts); ml = uni(ml); todo = uni(todo); lv = __builtin_amdgcn_readfirstlane(lv);
                         if (!ts) break;                  // nothing left (or levels that do not end: not our records)
+                        todo &= ~ml;                     // (a level left for its class-5/6 lanes is still in `todo`)
                         --lv;                            // (the loop's increment follows)
                     }
 #else
@@ -1280,9 +1362,6 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
             { const uint32_t ix = i0 + 128u + lane; rB = recs[ix < n ? ix : n - 1u]; }
             asm volatile("" ::: "memory");
             const uint32_t endy = dy + M;                // biased end of the sequence
-            // the records go to the resolver through LDS (slot re-use: the stager is at most NS < NB tickets, i.e. batches, ahead)
-            if (ticket >= NS) wait_resolved(ticket - NS + 1u);
-            rslots[(i0 >> 6) % NB][lane] = r;
             for (uint32_t s_i = 0; s_i < nsub && !gave_up; ++s_i) {
                 const unsigned long long msub = __ballot(sub == s_i);
                 if (!msub) { gave_up = true; if (lane == 0u) flag_set(3, 1u); break; }      // (records that do not number their sub-batches 0, 1, 2 ...: not ours)
