@@ -101,8 +101,9 @@ LZF_V6_VARIANTS(LZF_EXT6)
 //   records   one wave per tile: decode every token, absolute output positions, error checks, LITERALS -> out, and per
 //             batch of 64 sequences the dependency level of every match (level k copies only from bytes that are final
 //             once levels < k are done), its sub-batch and length class: one 16-byte record per sequence, final form
-//   resolve   one wave per job, the only serial stage: ring of the recent output in LDS (filled with the literals
-//             already in place), per batch one LDS round per dependency level, flush with aligned 16-byte stores
+//   resolve   two waves per job, the only serial stage: ring of the recent output in LDS (filled with the literals
+//             already in place by the stager wave, flushed by it with aligned 16-byte stores), per batch one LDS round
+//             per dependency level by the resolver wave (a hand-scheduled loop)
 // A job that is not eligible, or in which any stage meets something it does not handle (every DecodeError, capacity,
 // arena exhausted), is left to the pair kernel, which runs last and skips the jobs the pipeline finished.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -125,7 +126,7 @@ struct seg_ctx {
     unsigned long long* rec_top; // bump pointer into the arena
     uint64_t rec_cap;
     uint32_t n_jobs, maxch, maxtile, max_in, min_in;
-    uint32_t ring_bytes;         // LDS ring of the resolve stage (32 / 64 / 128 KiB): the levels stage classes the records for it
+    uint32_t ring_bytes;         // LDS ring of the resolve stage (32 / 64 / 128 KiB): the records stage classes the sequences for it
 };
 constexpr uint32_t kSegRegion = 256, kSegChunk = 64u * kSegRegion, kSegOverlap = 2048, kSegStride = kSegChunk - kSegOverlap;
 constexpr uint32_t kSegChunkWords = kSegChunk / 32u, kSegTile = 2048;

@@ -1,9 +1,9 @@
 // lz4_decompress_seg.hip — raw::decompress_raw (src/raw/decompress.rs:58-138) for gfx950 with ONE BLOCK DECODED BY MANY
-// WAVEFRONTS: the segmented pipeline of kernels.h (plan, parse, seam, tilesum, scan, records, levels, resolve).
+// WAVEFRONTS: the segmented pipeline of kernels.h (plan, parse, seam, tilesum, scan, records + levels, resolve).
 //
 // Why: a block is a serial chain twice over — the position of a token depends on every token before it
 // (decompress.rs:61-71), and a match copies bytes an earlier match produced (:80-138; on text the chain of dependent
-// matches is ~1/16 of the sequences long, tools/seg_depth.c).  One workgroup per block therefore needs ~20 ms per 4 MiB
+// matches is ~1/11 of the sequences long in windows of 64, tools/seg_depth.c).  One workgroup per block therefore needs ~20 ms per 4 MiB
 // block whatever the load.  Here everything that is not the second chain is spread over the chip:
 //   * the first chain is cut by SPECULATION: a token walk started at an arbitrary byte is on the true chain within 1-2 KB
 //     (tools/seq_stats.c), so every 16 KiB chunk is parsed on its own from its first byte and the chains are joined where
@@ -852,10 +852,12 @@ __global__ __launch_bounds__(64) void lzf_seg_records_kernel(seg_ctx c) {
 // The STAGER (wave 1) does everything that is not the dependency chain: the ring's granules in from `out` (the literals are
 // there), finished granules out to HBM, the few sources that are older than the ring (class 7: from HBM), sequences larger
 // than a sub-batch (class 8: HBM -> HBM, then the ring's history is read back).  The RESOLVER (wave 0) runs the rounds of
-// sub-batch after sub-batch: one LDS round trip per dependency level.  Both read the records (levels stage) on their own.
+// sub-batch after sub-batch: one LDS round trip per dependency level.  Both read the records (records stage) from HBM on
+// their own, two batches ahead of their use.
 // Tickets = sub-batches in stream order: the stager publishes ticket t with ctl[0] = t + 1 after its LDS writes, the
 // resolver answers ctl[1] = t + 1 after its own; LDS executes one wave's accesses in order, so a flag is never seen before
-// the data.  The stager runs at most NS tickets ahead; the levels stage classed the sources with that fetch-ahead in mind.
+// the data.  The stager runs at most NS tickets ahead (and loads the granules behind its fill pointer one sub-batch early);
+// the records stage classed the sources with that fetch-ahead in mind.
 template <int R>
 __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
     constexpr uint32_t kMask = (uint32_t)R - 1u;
