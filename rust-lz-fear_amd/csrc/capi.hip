@@ -108,6 +108,10 @@ bool seg_alloc(SegScratch& s, const lzf_decompress_job* d_jobs, lzf_job_result* 
     // the ring of a block: 128 KiB holds every distance LZ4 can express (no read-backs from HBM) while a CU has one block,
     // 64 / 32 KiB with read-backs for the oldest few per cent of the sources beyond that
     c.ring_bytes = n <= cu_count() ? 131072u : n <= 2u * cu_count() ? 65536u : 32768u;
+#ifdef LZF_ANALYSIS      // LZF_SEG_RING=32768|65536|131072: a ring size whatever the batch (one block per CU with the small rings: the stager's share)
+    { static const uint32_t ring = [] { const char* e = getenv("LZF_SEG_RING"); return e ? (uint32_t)atol(e) : 0u; }();
+      if (ring == 32768u || ring == 65536u || ring == 131072u) c.ring_bytes = ring; }
+#endif
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_st = take(sizeof(lzf::seg_job) * (size_t)n);

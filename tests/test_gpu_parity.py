@@ -276,6 +276,22 @@ def test_segmented_pipeline_mixed_batch():
     assert nerr >= 2
 
 
+@pytest.mark.parametrize("seed,nseq", [(41, 30000), (42, 60000), (43, 120000)])
+def test_segmented_pipeline_every_copy_class(seed, nseq):
+    """Handcrafted streams that hit every copy path of the resolver (lz4_decompress_seg.hip): the four two-ended sizes with and
+    without run-length offsets (1, 2, 4 — classes 1-4 and 9-12), long run-length matches stored by the whole wave, overlapping
+    ones, 65..160-byte matches alone and four or more to a level, matches of thousands of bytes — at every ring position (the
+    streams decode to several MiB).  The oracle agrees with the generator; the GPU with both."""
+    blk, out = vectors.synth_stream(seed, nseq, "classes")
+    assert len(blk) >= 65536                                          # inside the pipeline's window
+    erc, eout = o.decompress_raw(blk, limit=len(out), cap=len(out) + len(blk) + 64)
+    assert erc == 0 and eout == out
+    items = [dict(input=blk, limit=len(out), out_cap=len(out) + len(blk) + 64)] * 3     # (three jobs: different output alignments)
+    for rc, got in gpu_decompress(items):
+        assert rc == 0 and got == out
+    assert ffi.lib().lzf_last_decompress_launch().decode().startswith("segmented")
+
+
 @pytest.mark.parametrize("copies", [25, 55])
 def test_segmented_pipeline_smaller_rings(copies):
     """More than one block per CU: 64 KiB (up to two per CU) and 32 KiB rings (beyond), where the oldest sources are read

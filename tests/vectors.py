@@ -95,6 +95,12 @@ def synth_stream(seed, n_seq, profile):
         elif profile == "long":
             L = int(rng.integers(0, 6000)) if r < 0.3 else int(rng.integers(0, 40))
             M = 4 + (int(rng.integers(0, 90000)) if r > 0.8 else int(rng.integers(0, 60)))
+        elif profile == "classes":        # every copy path of the segmented pipeline's resolver: the four two-ended sizes, the
+            L = int(rng.integers(0, 7)) if r < 0.95 else int(rng.integers(7, 200))       # same for run-length offsets, long
+            b = rng.random()                                                              # and overlapping ones, bursts of 65..160
+            M = (int(rng.integers(4, 8)) if b < 0.2 else int(rng.integers(8, 17)) if b < 0.4 else int(rng.integers(17, 33)) if b < 0.55 else
+                 int(rng.integers(33, 65)) if b < 0.7 else int(rng.integers(65, 161)) if b < 0.85 else int(rng.integers(161, 700)) if b < 0.985 else
+                 int(rng.integers(2000, 9000)))
         else:                             # "rle": tiny offsets, overlapping copies
             L = int(rng.integers(0, 5))
             M = 4 + int(rng.integers(0, 300))
@@ -102,7 +108,13 @@ def synth_stream(seed, n_seq, profile):
             L = 4
         lit = bytes(rng.integers(0, 256, L, dtype=np.uint8))
         avail = len(out) + L
-        if profile == "rle" or rng.random() < 0.15:
+        if profile == "classes":
+            q = rng.random()
+            if q < 0.4: off = int(rng.choice([1, 2, 4]))
+            elif q < 0.55: off = int(rng.integers(1, 65))
+            elif q < 0.8: off = int(rng.integers(200, 66000))          # (far: the same level for a run of them)
+            else: off = int(rng.integers(1, 66000))
+        elif profile == "rle" or rng.random() < 0.15:
             off = int(rng.integers(1, min(avail, 9) + 1)) if avail >= 1 else 1
         elif rng.random() < 0.1:
             off = min(avail, 65535 - int(rng.integers(0, 50)))
