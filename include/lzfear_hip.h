@@ -15,7 +15,10 @@
  * Memory: every pointer in a job is a DEVICE pointer (HBM) unless the function name ends in
  * `_host`.  The library never retains pointers past a call and owns no global state besides
  * the staging memory of the `_host` helpers and the frame layer (one pinned slab and device
- * scratch, kept between calls; lzf_frame_release_scratch() of lzfear_frame.h frees them).  There is NO CPU fallback: every entry point
+ * scratch, kept between calls; lzf_frame_release_scratch() of lzfear_frame.h frees them) and ONE process-wide setting: the batch
+ * calls take their scratch from the device's default stream-ordered memory pool and raise that pool's release threshold
+ * (hipMemPoolAttrReleaseThreshold) to "keep", once per device — without it every call would go back to the device allocator
+ * and wait for whatever is running.  There is NO CPU fallback: every entry point
  * returns LZF_E_NO_DEVICE when no HIP device is usable.
  */
 #ifndef LZFEAR_HIP_H

@@ -55,6 +55,9 @@ def build_library(force=False, verbose=False, defines=(), out=None, analysis=Fal
     if (analysis or any(d.startswith("LZF_DBG") for d in defines)) and "LZF_ANALYSIS" not in defines:
         defines.append("LZF_ANALYSIS")
     analysis = "LZF_ANALYSIS" in defines
+    extra = sorted(d for d in defines if d != "LZF_ANALYSIS")
+    if out is None and extra:       # an instrumented build never takes the name (and the up-to-date check) of the plain analysis library
+        out = os.path.join(PKG_DIR, "liblzfear_hip_" + hashlib.sha1(" ".join(extra).encode()).hexdigest()[:10] + ".so")
     out = out or (ANALYSIS_LIB_PATH if analysis else LIB_PATH)
     srcs_t = max([os.path.getmtime(_path(s)) for s in _sources(analysis)] + [_newest_header()])
     if not force and os.path.exists(out) and os.path.getmtime(out) >= srcs_t:

@@ -57,6 +57,13 @@ uint32_t cu_count() {
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// stream-ordered scratch of a batch call: handed back to the pool on every way out of the call (a failed launch included)
+struct AsyncScratch {
+    void* p = nullptr; hipStream_t st = nullptr;
+    ~AsyncScratch() { if (p) { (void)hipFreeAsync(p, st); } }
+    hipError_t release() { void* q = p; p = nullptr; return q ? hipFreeAsync(q, st) : hipSuccess; }
+};
+
 // The batch calls take their scratch (launch orders, cost probes) from the stream-ordered pool.  By default the pool hands its
 // memory back at every synchronisation point, so the next call allocates from the device again — which waits for whatever is
 // running.  Keep what the pool has: a later hipMallocAsync on the same stream re-uses it without touching the device.
@@ -207,7 +214,8 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
 #endif
     const bool fresh_only = use_compact && (table_kinds & LZF_KINDS_U32_FRESH_ONLY);
     uint32_t* perm = nullptr;
-    void* scratch = nullptr;
+    AsyncScratch scratch_owner; scratch_owner.st = st;
+    void*& scratch = scratch_owner.p;
     // the cost of a compress job is not known from its size: probe (aux_kernels.hip), then longest first
     if (use_order && use_compact && (table_kinds & LZF_KINDS_U32) && (use_order == 2u || n_jobs > 18u * cu_count())) {
         const uint32_t piece = 65536u, parts = 1u;      // one 64 KiB piece from the middle of each payload (more or smaller pieces order no better)
@@ -235,7 +243,7 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
     }
     if (table_kinds & LZF_KINDS_U16)
         LAUNCH(k_general_u16, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, 0u, (const uint32_t*)perm);
-    if (scratch) HIP_TRY(hipFreeAsync(scratch, st));
+    HIP_TRY(scratch_owner.release());
     return LZF_OK;
 }
 
@@ -258,9 +266,10 @@ int lzf_decompress_batch_sized(const lzf_decompress_job* d_jobs, lzf_job_result*
     if (forced != kVariantAuto) perm_ok = analysis_perm_ok(forced);
 #endif
     // more blocks than the chip holds at once: longest (most compressed bytes) first
-    uint32_t* perm = nullptr;
+    AsyncScratch perm_owner; perm_owner.st = st;
+    uint32_t*& perm = reinterpret_cast<uint32_t*&>(perm_owner.p);
     if (perm_ok && (use_order == 2u || (use_order == 1u && n_jobs > 8u * cu_count()))) {
-        if (hipMallocAsync(reinterpret_cast<void**>(&perm), sizeof(uint32_t) * (size_t)n_jobs, st) != hipSuccess) { (void)hipGetLastError(); perm = nullptr; }   // (then: the caller's order)
+        if (hipMallocAsync(&perm_owner.p, sizeof(uint32_t) * (size_t)n_jobs, st) != hipSuccess) { (void)hipGetLastError(); perm_owner.p = nullptr; }   // (then: the caller's order)
         if (perm) LAUNCH(lzf::lzf_order_by_input_len_kernel, dim3(1), dim3(1024), 0, st, d_jobs, perm, n_jobs);
     }
     const uint32_t* cperm = perm;
@@ -268,7 +277,7 @@ int lzf_decompress_batch_sized(const lzf_decompress_job* d_jobs, lzf_job_result*
     if (forced != kVariantAuto) {
         g_last_decompress = "analysis variant (LZF_DECOMPRESS_KERNEL)";
         rc = analysis_launch_decompress(forced, d_jobs, d_results, n_jobs, cperm, st);
-        if (perm) HIP_TRY(hipFreeAsync(perm, st));
+        HIP_TRY(perm_owner.release());
         return rc;
     }
 #endif
@@ -287,7 +296,7 @@ int lzf_decompress_batch_sized(const lzf_decompress_job* d_jobs, lzf_job_result*
         if (used) g_last_decompress = n_jobs <= cu_count() ? "segmented: lzf_seg_resolve_pair_kernel<131072> + lzf_decompress_paired_kernel<4096,48,640>"
                                      : n_jobs <= 2u * cu_count() ? "segmented: lzf_seg_resolve_pair_kernel<65536> + lzf_decompress_paired_kernel<4096,48,640>"
                                                                  : "segmented: lzf_seg_resolve_pair_kernel<32768> + lzf_decompress_paired_kernel<4096,48,640>";
-        if (rc != LZF_OK || used) { if (perm) HIP_TRY(hipFreeAsync(perm, st)); return rc; }
+        if (rc != LZF_OK || used) { HIP_TRY(perm_owner.release()); return rc; }
     }
     // The producer/consumer pair kernel, with 48-byte regions while every block's workgroup is resident at once (lowest
     // latency per block: the copy stage is the critical path, the parse rides along) and 24-byte regions beyond that
@@ -302,7 +311,7 @@ int lzf_decompress_batch_sized(const lzf_decompress_job* d_jobs, lzf_job_result*
         LAUNCH(k_paired24, dim3(n_jobs), dim3(128), 0, st, d_jobs, d_results, n_jobs, cperm, (const lzf::seg_job*)nullptr);
     else
         LAUNCH(k_staged16, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, cperm);
-    if (perm) HIP_TRY(hipFreeAsync(perm, st));
+    HIP_TRY(perm_owner.release());
     return LZF_OK;
 }
 

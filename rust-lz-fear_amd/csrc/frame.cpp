@@ -17,6 +17,8 @@
 #include "host_staging.h"
 
 namespace {
+// a HIP failure inside a driver: nothing asynchronous may still read the caller's (or this call's) host arrays when it returns
+inline int fail_hip() { (void)hipDeviceSynchronize(); return LZF_E_HIP; }
 
 inline uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 inline void wr32(uint8_t* p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
@@ -92,7 +94,7 @@ int seeded_template(const uint8_t* dict, size_t dict_len, lzf_u32_table* host_ta
     void *d_dict = nullptr, *d_tab = nullptr;
     if (hipMalloc(&d_dict, dict_len) != hipSuccess || hipMalloc(&d_tab, sizeof(lzf_u32_table)) != hipSuccess) {
         if (d_dict) (void)hipFree(d_dict);
-        return LZF_E_HIP;
+        return fail_hip();
     }
     int rc = LZF_OK;
     if (hipMemcpy(d_dict, dict, dict_len, hipMemcpyHostToDevice) != hipSuccess) rc = LZF_E_HIP;
@@ -314,7 +316,7 @@ int lzf_frame_reader_decode_block(lzf_frame_reader* r, const uint8_t* dict, size
     uint8_t* d_out = static_cast<uint8_t*>(sg.device(1, cap));
     uint8_t* d_pre = static_cast<uint8_t*>(sg.device(10, prefix_len));
     uint8_t* d_meta = static_cast<uint8_t*>(sg.device(5, 1024));
-    if (!cs || !d_in || !d_out || !d_pre || !d_meta) return LZF_E_HIP;
+    if (!cs || !d_in || !d_out || !d_pre || !d_meta) return fail_hip();
 #define HIPR(e) do { if ((e) != hipSuccess) { (void)hipDeviceSynchronize(); return LZF_E_HIP; } } while (0)
     HIPR(hipMemcpyAsync(d_in, data, bl, hipMemcpyHostToDevice, cs));
     if (bsum) {
@@ -416,7 +418,7 @@ struct Lists {
     size_t add(const void* p, size_t bytes) { const size_t o = h.size(); h.resize(up256(o + bytes)); if (bytes && p) memcpy(h.data() + o, p, bytes); off.push_back(o); return off.size() - 1; }
     int upload(Staging& sg, int slot, hipStream_t st) {
         d = static_cast<uint8_t*>(sg.device(slot, h.size()));
-        if (!d) return LZF_E_HIP;
+        if (!d) return fail_hip();
         if (!h.empty()) HIPOK(hipMemcpyAsync(d, h.data(), h.size(), hipMemcpyHostToDevice, st));
         return LZF_OK;
     }
@@ -524,8 +526,8 @@ static int compress_many_pass(const lzf_settings* s, uint32_t n_frames, const ui
     std::lock_guard<std::mutex> guard(sg.lock());
     TRACE_BEGIN();
     hipStream_t cs = sg.stream(0), hs = sg.stream(3);
-    if (!cs || !hs) return LZF_E_HIP;
-    if (!sg.pinned(in_total > pack_bound ? in_total : pack_bound)) return LZF_E_HIP;
+    if (!cs || !hs) return fail_hip();
+    if (!sg.pinned(in_total > pack_bound ? in_total : pack_bound)) return fail_hip();
     TRACE("c: pinned slab");
     std::vector<lzf_compress_job> jobs(n_jobs);
     std::vector<uint32_t> job_frame(n_jobs), job_block(n_jobs);
@@ -554,7 +556,7 @@ static int compress_many_pass(const lzf_settings* s, uint32_t n_frames, const ui
         const size_t oa = fa < n_frames ? fr[fa].out0 : pack_bound, ob = fb < n_frames ? fr[fb].out0 : pack_bound;
         void* const di = sg.device(S_IN_G + (int)g, ib - ia);
         void* const dob = sg.device(S_OUT_G + (int)g, ob - oa);
-        if (!di || !dob) return LZF_E_HIP;
+        if (!di || !dob) return fail_hip();
         din_b[g] = reinterpret_cast<uintptr_t>(di) - ia; dout_b[g] = reinterpret_cast<uintptr_t>(dob) - oa;
         for (uint32_t f = fa; f < fb; ++f) fr[f].grp = g;
     }
@@ -573,10 +575,10 @@ static int compress_many_pass(const lzf_settings* s, uint32_t n_frames, const ui
     if (!indep) {
         for (uint32_t f = 0; f < n_frames; ++f) if (fr[f].nb) lf_index[f] = n_linked++;
         d_tabs = static_cast<lzf_u32_table*>(sg.device(S_TABS, sizeof(lzf_u32_table) * (size_t)(n_linked ? n_linked : 1)));
-        if (!d_tabs) return LZF_E_HIP;
+        if (!d_tabs) return fail_hip();
     } else if (dict_len >= 8) {
         d_tmpl = sg.device(S_TMPL, sizeof tmpl);
-        if (!d_tmpl) return LZF_E_HIP;
+        if (!d_tmpl) return fail_hip();
         HIPOK(hipMemcpyAsync(d_tmpl, &tmpl, sizeof tmpl, hipMemcpyHostToDevice, cs));
     }
 
@@ -629,12 +631,12 @@ static int compress_many_pass(const lzf_settings* s, uint32_t n_frames, const ui
     }
     lzf_compress_job* const d_jobs = static_cast<lzf_compress_job*>(sg.device(S_JOBS, sizeof(lzf_compress_job) * n_jobs));
     lzf_job_result* const d_res = static_cast<lzf_job_result*>(sg.device(S_RES, sizeof(lzf_job_result) * n_jobs));
-    if (!d_jobs || !d_res) return LZF_E_HIP;
+    if (!d_jobs || !d_res) return fail_hip();
     for (size_t q = 0; q < n_jobs; ++q) jobs[q].out = reinterpret_cast<uint8_t*>(dout_b[fr[job_frame[q]].grp] + job_out_off[q]);
     // results come back through the pinned mailbox: [block results | content hashes | block checksums]
     const size_t mb_res = 0, mb_chash = up256(sizeof(lzf_job_result) * n_jobs), mb_sums = mb_chash + up256(sizeof(uint32_t) * n_frames);
     uint8_t* const mbox = sg.mailbox(mb_sums + sizeof(uint32_t) * n_jobs);
-    if (!mbox) return LZF_E_HIP;
+    if (!mbox) return fail_hip();
     const lzf_job_result* const res = reinterpret_cast<const lzf_job_result*>(mbox + mb_res);
     TRACE("c: layout + scratch");
     // ---- in: small arrays first, then group after group: its bytes (pieces, asynchronous), its launches, its results
@@ -646,7 +648,7 @@ static int compress_many_pass(const lzf_settings* s, uint32_t n_frames, const ui
         HIPOK(hipMemcpyAsync(d_tabs, h_tabs.data(), sizeof(lzf_u32_table) * n_linked, hipMemcpyHostToDevice, cs));
         d_tabptr = static_cast<void**>(sg.device(S_TABPTR, sizeof(void*) * n_jobs));
         d_adds = static_cast<uint64_t*>(sg.device(S_ADDS, sizeof(uint64_t) * n_jobs));
-        if (!d_tabptr || !d_adds) return LZF_E_HIP;
+        if (!d_tabptr || !d_adds) return fail_hip();
         HIPOK(hipMemcpyAsync(d_tabptr, h_tabptr.data(), sizeof(void*) * n_jobs, hipMemcpyHostToDevice, cs));
         HIPOK(hipMemcpyAsync(d_adds, h_adds.data(), sizeof(uint64_t) * n_jobs, hipMemcpyHostToDevice, cs));
     }
@@ -801,7 +803,7 @@ inline size_t block_out_bound(size_t bmax, size_t len) { const size_t e = 255 * 
 int decompress_group(Staging& sg, std::vector<DFrame>& fr, uint32_t f0, uint32_t f1, const uint8_t* const* in, const size_t* in_len,
                      const uint8_t* dict, size_t dict_len, uint8_t* const* out, const size_t* out_cap, size_t* out_len, size_t* consumed, int* status) {
     hipStream_t cs = sg.stream(0), hs = sg.stream(3);
-    if (!cs || !hs) return LZF_E_HIP;
+    if (!cs || !hs) return fail_hip();
     TRACE_BEGIN();
     size_t in_total = 0, out_total = 0, max_steps = 0, n_sums = 0, pack_bound = 0;
     uint32_t n_chain = 0;
@@ -824,12 +826,12 @@ int decompress_group(Staging& sg, std::vector<DFrame>& fr, uint32_t f0, uint32_t
             for (size_t i = 0; i < nb; ++i) if (F.blocks[i].compressed) { F.slot[i] = out_total; out_total = up256(out_total + block_out_bound(bmax, F.blocks[i].len) + F.blocks[i].len); }   // limit + C
         }
     }
-    if (!sg.pinned(in_total > pack_bound ? in_total : pack_bound)) return LZF_E_HIP;
+    if (!sg.pinned(in_total > pack_bound ? in_total : pack_bound)) return fail_hip();
     uint8_t* const din = static_cast<uint8_t*>(sg.device(S_IN, in_total));
     uint8_t* const dout = static_cast<uint8_t*>(sg.device(S_OUT, out_total));
     uint8_t* d_dict = nullptr;
-    if (!din || !dout) return LZF_E_HIP;
-    if (dict_len) { d_dict = static_cast<uint8_t*>(sg.device(S_DICT, dict_len)); if (!d_dict) return LZF_E_HIP; HIPOK(hipMemcpyAsync(d_dict, dict, dict_len, hipMemcpyHostToDevice, cs)); }
+    if (!din || !dout) return fail_hip();
+    if (dict_len) { d_dict = static_cast<uint8_t*>(sg.device(S_DICT, dict_len)); if (!d_dict) return fail_hip(); HIPOK(hipMemcpyAsync(d_dict, dict, dict_len, hipMemcpyHostToDevice, cs)); }
     // ---- job list ordered by step: step 0 = every block of the independent frames + block 0 of the linked streams
     std::vector<lzf_decompress_job> jobs;
     std::vector<size_t> step_off;
@@ -869,7 +871,7 @@ int decompress_group(Staging& sg, std::vector<DFrame>& fr, uint32_t f0, uint32_t
     // results come back through the pinned mailbox: [block results | block checksums | content hashes]
     const size_t mb_sums = up256(sizeof(lzf_job_result) * n_jobs), mb_chash = mb_sums + up256(sizeof(uint32_t) * n_sums);
     uint8_t* const mbox = sg.mailbox(mb_chash + sizeof(uint32_t) * (f1 - f0));
-    if (!mbox) return LZF_E_HIP;
+    if (!mbox) return fail_hip();
     const lzf_job_result* const res = reinterpret_cast<const lzf_job_result*>(mbox);
     const uint32_t* const sums = reinterpret_cast<const uint32_t*>(mbox + mb_sums);
     const uint32_t* const chash = reinterpret_cast<const uint32_t*>(mbox + mb_chash);
@@ -892,13 +894,13 @@ int decompress_group(Staging& sg, std::vector<DFrame>& fr, uint32_t f0, uint32_t
     if (n_jobs || n_chain) {
         lzf_decompress_job* const d_jobs = static_cast<lzf_decompress_job*>(sg.device(S_JOBS, sizeof(lzf_decompress_job) * n_jobs));
         lzf_job_result* const d_res = static_cast<lzf_job_result*>(sg.device(S_RES, sizeof(lzf_job_result) * n_jobs));
-        if (!d_jobs || !d_res) return LZF_E_HIP;
+        if (!d_jobs || !d_res) return fail_hip();
         if (n_jobs) HIPOK(hipMemcpyAsync(d_jobs, jobs.data(), sizeof(lzf_decompress_job) * n_jobs, hipMemcpyHostToDevice, cs));
         lzf_chain_step* d_steps = nullptr; lzf_chain_state* d_state = nullptr;
         if (n_chain) {
             d_steps = static_cast<lzf_chain_step*>(sg.device(S_STEPS, sizeof(lzf_chain_step) * csteps.size()));
             d_state = static_cast<lzf_chain_state*>(sg.device(S_STATE, sizeof(lzf_chain_state) * n_chain));
-            if (!d_steps || !d_state) return LZF_E_HIP;
+            if (!d_steps || !d_state) return fail_hip();
             HIPOK(hipMemcpyAsync(d_steps, csteps.data(), sizeof(lzf_chain_step) * csteps.size(), hipMemcpyHostToDevice, cs));
             HIPOK(hipMemsetAsync(d_state, 0, sizeof(lzf_chain_state) * n_chain, cs));
         }
@@ -970,7 +972,7 @@ int decompress_group(Staging& sg, std::vector<DFrame>& fr, uint32_t f0, uint32_t
     }
     if (!r_src.empty() || !dev_hash.empty()) {
         uint8_t* const dpack = static_cast<uint8_t*>(sg.device(S_PACK, pk_total));
-        if (!dpack) return LZF_E_HIP;
+        if (!dpack) return fail_hip();
         std::vector<uint8_t*> r_dst(r_src.size());
         for (size_t i = 0; i < r_src.size(); ++i) r_dst[i] = dpack + pk_pos[i];
         std::vector<const uint8_t*> hp; std::vector<uint64_t> hn;

@@ -182,7 +182,11 @@ hipError_t Staging::upload(const std::vector<Seg>& segs, size_t slab_bytes, uint
     if (!pin) return hipErrorOutOfMemory;
     hipStream_t c1 = stream(1), c2 = stream(2);
     if (!c1 || !c2) return hipErrorUnknown;
-    if (total <= kInline) {
+    size_t span_a = SIZE_MAX, span_b = 0;
+    for (const Seg& s : segs) if (s.len) { if (s.slab_off < span_a) span_a = s.slab_off; if (s.slab_off + s.len > span_b) span_b = s.slab_off + s.len; }
+    // (one copy over the whole span only while the span is mostly payload: sparse segments — small payloads in large slots —
+    //  take the piecewise path, which moves what the segments cover)
+    if (total <= kInline && span_b - span_a <= 2 * total) {
         size_t a = SIZE_MAX, b = 0;
         for (const Seg& s : segs) if (s.len) { memcpy(pin + s.slab_off, s.host, s.len); if (s.slab_off < a) a = s.slab_off; if (s.slab_off + s.len > b) b = s.slab_off + s.len; }
         TRY(hipMemcpyAsync(d_base + a, pin + a, b - a, hipMemcpyHostToDevice, c1));
@@ -234,7 +238,9 @@ hipError_t Staging::download(const std::vector<Seg>& segs, size_t slab_bytes, co
     if (!total) { if (before) TRY(hipStreamSynchronize(before)); if (ready) TRY(hipEventSynchronize(ready)); return hipSuccess; }
     uint8_t* pin = pinned(slab_bytes);
     if (!pin) return hipErrorOutOfMemory;
-    if (total <= kInline) {
+    size_t span_a = SIZE_MAX, span_b = 0;
+    for (const Seg& s : segs) if (s.len) { if (s.slab_off < span_a) span_a = s.slab_off; if (s.slab_off + s.len > span_b) span_b = s.slab_off + s.len; }
+    if (total <= kInline && span_b - span_a <= 2 * total) {
         size_t a = SIZE_MAX, b = 0;
         for (const Seg& s : segs) if (s.len) { if (s.slab_off < a) a = s.slab_off; if (s.slab_off + s.len > b) b = s.slab_off + s.len; }
         TRY(hipMemcpyAsync(pin + a, d_base + a, b - a, hipMemcpyDeviceToHost, c1));
