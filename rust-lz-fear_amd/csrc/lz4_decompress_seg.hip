@@ -837,7 +837,13 @@ __global__ __launch_bounds__(64) void lzf_seg_records_kernel(seg_ctx c) {
                 const uint32_t last_sub = __builtin_amdgcn_readlane(sub, (nb - 1u) & 63u);
                 u32x4 w;
                 w[0] = act ? M : 0u; w[1] = (act ? mo : last_end) + rb;
-                w[2] = (act ? sub : last_sub) | ((act ? lvl : 0u) << 16) | ((act ? cls : 0u) << 24); w[3] = act ? off : 0u;
+                // bits 8..15: the resolver's round masks as flags (one v_and + v_cmp each there): 1 four-byte pieces (classes 1, 9),
+                // 2 first pair of eight-byte pieces (2-4, 10-12), 4 second pair (3, 4, 11, 12), 8 third and fourth (4, 12),
+                // 16 leaves the loop (5, 6), 32 run-length (9-12)
+                const uint32_t fl = !act ? 0u : ((cls == 1u || cls == 9u) ? 1u : 0u) | (((cls >= 2u && cls <= 4u) || (cls >= 10u && cls <= 12u)) ? 2u : 0u) |
+                                    ((cls == 3u || cls == 4u || cls == 11u || cls == 12u) ? 4u : 0u) | ((cls == 4u || cls == 12u) ? 8u : 0u) |
+                                    ((cls == 5u || cls == 6u) ? 16u : 0u) | ((cls >= 9u && cls <= 12u) ? 32u : 0u);
+                w[2] = (act ? sub : last_sub) | (fl << 8) | ((act ? lvl : 0u) << 16) | ((act ? cls : 0u) << 24); w[3] = act ? off : 0u;
                 recs[tbase + i0 + lane] = w;
             }
         }
@@ -863,8 +869,10 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
     constexpr uint32_t kMask = (uint32_t)R - 1u;
     constexpr uint32_t kSpan = (uint32_t)R / 8u;       // output bytes one sub-batch may produce
     constexpr uint32_t NS = 3;                         // tickets the stager may be ahead
-    __shared__ __attribute__((aligned(16))) uint8_t ring[R];
-    __shared__ uint32_t ctl[4];                        // [0] staged tickets, [1] resolved tickets
+    // (the ring starts 64 bytes into the workgroup's LDS: an address 32 bytes in front of a ring position is never negative)
+    __shared__ __attribute__((aligned(16))) uint8_t lds_all[64 + R];
+    uint8_t* const ring = lds_all + 64;
+    uint32_t* const ctl = reinterpret_cast<uint32_t*>(lds_all);      // [0] staged tickets, [1] resolved tickets, [3] a wave gave up
     const uint32_t j = blockIdx.x;
     if (j >= c.n_jobs) return;
     const seg_job sj = c.st[j];
@@ -959,11 +967,11 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
 #if !defined(LZF_SEG_NOASM) && !defined(LZF_SEG_DBG_SKIP) && !defined(LZF_SEG_NORLE)
             // classes 9..12: run-length matches (offset 1, 2 or 4) of the same four sizes — stored like 1..4, the registers filled
             // with the pattern (the first bytes read, spread by v_perm_b32; rotated for the piece that ends the match)
-            const unsigned long long mR_b = __ballot(cls >= 9u && cls <= 12u);
-            const unsigned long long mA_b = __ballot(cls == 1u || cls == 9u), m2_b = __ballot((cls >= 2u && cls <= 4u) || (cls >= 10u && cls <= 12u)),
-                                     m3_b = __ballot(cls == 3u || cls == 4u || cls == 11u || cls == 12u),
-                                     m4_b = __ballot(cls == 4u || cls == 12u), mS_b = __ballot(cls == 5u || cls == 6u);
-            const uint32_t rsel = off == 1u ? 0u : off == 2u ? 0x01000100u : 0x03020100u, rsh = M & (off - 1u);
+            const uint32_t fl = r[2] >> 8;              // (the records stage's flags; padding lanes carry none)
+            const unsigned long long mA_b = __ballot((fl & 1u) != 0u), m2_b = __ballot((fl & 2u) != 0u), m3_b = __ballot((fl & 4u) != 0u),
+                                     m4_b = __ballot((fl & 8u) != 0u), mS_b = __ballot((fl & 16u) != 0u), mR_b = __ballot((fl & 32u) != 0u);
+            uint32_t rsel = 0, rsh = 0;                  // (only batches with run-length lanes pay for these)
+            if (mR_b) { rsel = off == 1u ? 0u : off == 2u ? 0x01000100u : 0x03020100u; rsh = M & (off - 1u); }
 #else
             // (the compiler's loop: the run-length classes take the general path (a) below)
             const unsigned long long mA_b = __ballot(cls == 1u), m2_b = __ballot(cls >= 2u && cls <= 4u), m3_b = __ballot(cls == 3u || cls == 4u),
@@ -1001,6 +1009,7 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                         if ((mR_b | mS_b) & msub)
                         asm volatile(
                             "s_mov_b64 %[sv], exec\n\t"
+                            ".p2align 6\n\t"                                     // (the loop starts an instruction-cache line: its time must not depend on what is compiled around it)
                             "Lloop%=:\n\t"
                             "v_cmp_eq_u32_e32 vcc, %[lv], %[vl]\n\t"
                             "s_add_u32 %[lv], %[lv], 1\n\t"
@@ -1011,20 +1020,20 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
 #endif
                             "s_and_b64 exec, %[ml], %[mA]\n\t"
                             "ds_read_b32 v116, %[sa]\n\t"
-                            "ds_read_b32 v117, %[s1]\n\t"
+                            "ds_read_b32 v117, %[tsrc] offset:28\n\t"
                             "s_and_b64 exec, %[ml], %[m2]\n\t"
                             "ds_read_b64 v[100:101], %[sa]\n\t"
-                            "ds_read_b64 v[106:107], %[s3]\n\t"
+                            "ds_read_b64 v[106:107], %[tsrc] offset:24\n\t"
                             "s_and_b64 exec, %[ml], %[m3]\n\t"
                             "s_cbranch_execz Lr%=\n\t"
                             "ds_read_b64 v[102:103], %[sa] offset:8\n\t"
-                            "ds_read_b64 v[104:105], %[s16]\n\t"
+                            "ds_read_b64 v[104:105], %[tsrc] offset:16\n\t"
                             "s_and_b64 exec, %[ml], %[m4]\n\t"
                             "s_cbranch_execz Lr%=\n\t"
                             "ds_read_b64 v[108:109], %[sa] offset:16\n\t"
                             "ds_read_b64 v[110:111], %[sa] offset:24\n\t"
-                            "ds_read_b64 v[112:113], %[s32]\n\t"
-                            "ds_read_b64 v[114:115], %[s32] offset:8\n\t"
+                            "ds_read_b64 v[112:113], %[tsrc]\n\t"
+                            "ds_read_b64 v[114:115], %[tsrc] offset:8\n\t"
                             "Lr%=:\n\t"
                             "s_and_b64 exec, %[ml], %[mR]\n\t"
 #ifndef LZF_SEG_DBG_NOWAIT                                         // (analysis: the round without its LDS latency; wrong bytes)
@@ -1048,20 +1057,20 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                             "Lnr%=:\n\t"
                             "s_and_b64 exec, %[ml], %[mA]\n\t"
                             "ds_write_b32 %[da], v116\n\t"
-                            "ds_write_b32 %[d1], v117\n\t"
+                            "ds_write_b32 %[tdst], v117 offset:28\n\t"
                             "s_and_b64 exec, %[ml], %[m2]\n\t"
                             "ds_write_b64 %[da], v[100:101]\n\t"
-                            "ds_write_b64 %[d3], v[106:107]\n\t"
+                            "ds_write_b64 %[tdst], v[106:107] offset:24\n\t"
                             "s_and_b64 exec, %[ml], %[m3]\n\t"
                             "s_cbranch_execz Lw%=\n\t"
                             "ds_write_b64 %[da], v[102:103] offset:8\n\t"
-                            "ds_write_b64 %[d16], v[104:105]\n\t"
+                            "ds_write_b64 %[tdst], v[104:105] offset:16\n\t"
                             "s_and_b64 exec, %[ml], %[m4]\n\t"
                             "s_cbranch_execz Lw%=\n\t"
                             "ds_write_b64 %[da], v[108:109] offset:16\n\t"
                             "ds_write_b64 %[da], v[110:111] offset:24\n\t"
-                            "ds_write_b64 %[d32], v[112:113]\n\t"
-                            "ds_write_b64 %[d32], v[114:115] offset:8\n\t"
+                            "ds_write_b64 %[tdst], v[112:113]\n\t"
+                            "ds_write_b64 %[tdst], v[114:115] offset:8\n\t"
                             "Lw%=:\n\t"
                             "s_mov_b64 exec, %[sv]\n\t"
                             "s_and_b64 %[ts], %[ml], %[mS]\n\t"
@@ -1079,14 +1088,15 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                               , [nr] "+s"(n_rounds)
 #endif
                             : [mA] "s"(mA_b), [m2] "s"(m2_b), [m3] "s"(m3_b), [m4] "s"(m4_b), [mS] "s"(mS_b), [mR] "s"(mR_b), [vl] "v"(lvl), [rsel] "v"(rsel), [rsh] "v"(rsh),
-                              [sa] "v"(sa), [s1] "v"(sa + a1), [s3] "v"(sa + o3), [s16] "v"(sa + M - 16u), [s32] "v"(sa + M - 32u),
-                              [da] "v"(da), [d1] "v"(da + a1), [d3] "v"(da + o3), [d16] "v"(da + M - 16u), [d32] "v"(da + M - 32u)
+                              [sa] "v"(sa), [tsrc] "v"(sa + M - 32u),
+                              [da] "v"(da), [tdst] "v"(da + M - 32u)
                             : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113",
                               "v114", "v115", "v116", "v117");
                         else
                         asm volatile(
                             "s_mov_b64 %[sv], exec\n\t"
                             "s_mov_b64 %[ts], 0\n\t"
+                            ".p2align 6\n\t"                                     // (the loop starts an instruction-cache line: its time must not depend on what is compiled around it)
                             "Lloop%=:\n\t"
                             "v_cmp_eq_u32_e32 vcc, %[lv], %[vl]\n\t"
                             "s_add_u32 %[lv], %[lv], 1\n\t"
@@ -1097,38 +1107,38 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
 #endif
                             "s_and_b64 exec, %[ml], %[mA]\n\t"
                             "ds_read_b32 v116, %[sa]\n\t"
-                            "ds_read_b32 v117, %[s1]\n\t"
+                            "ds_read_b32 v117, %[tsrc] offset:28\n\t"
                             "s_and_b64 exec, %[ml], %[m2]\n\t"
                             "ds_read_b64 v[100:101], %[sa]\n\t"
-                            "ds_read_b64 v[106:107], %[s3]\n\t"
+                            "ds_read_b64 v[106:107], %[tsrc] offset:24\n\t"
                             "s_and_b64 exec, %[ml], %[m3]\n\t"
                             "s_cbranch_execz Lr%=\n\t"
                             "ds_read_b64 v[102:103], %[sa] offset:8\n\t"
-                            "ds_read_b64 v[104:105], %[s16]\n\t"
+                            "ds_read_b64 v[104:105], %[tsrc] offset:16\n\t"
                             "s_and_b64 exec, %[ml], %[m4]\n\t"
                             "s_cbranch_execz Lr%=\n\t"
                             "ds_read_b64 v[108:109], %[sa] offset:16\n\t"
                             "ds_read_b64 v[110:111], %[sa] offset:24\n\t"
-                            "ds_read_b64 v[112:113], %[s32]\n\t"
-                            "ds_read_b64 v[114:115], %[s32] offset:8\n\t"
+                            "ds_read_b64 v[112:113], %[tsrc]\n\t"
+                            "ds_read_b64 v[114:115], %[tsrc] offset:8\n\t"
                             "Lr%=:\n\t"
                             "s_waitcnt lgkmcnt(0)\n\t"
                             "s_and_b64 exec, %[ml], %[mA]\n\t"
                             "ds_write_b32 %[da], v116\n\t"
-                            "ds_write_b32 %[d1], v117\n\t"
+                            "ds_write_b32 %[tdst], v117 offset:28\n\t"
                             "s_and_b64 exec, %[ml], %[m2]\n\t"
                             "ds_write_b64 %[da], v[100:101]\n\t"
-                            "ds_write_b64 %[d3], v[106:107]\n\t"
+                            "ds_write_b64 %[tdst], v[106:107] offset:24\n\t"
                             "s_and_b64 exec, %[ml], %[m3]\n\t"
                             "s_cbranch_execz Lw%=\n\t"
                             "ds_write_b64 %[da], v[102:103] offset:8\n\t"
-                            "ds_write_b64 %[d16], v[104:105]\n\t"
+                            "ds_write_b64 %[tdst], v[104:105] offset:16\n\t"
                             "s_and_b64 exec, %[ml], %[m4]\n\t"
                             "s_cbranch_execz Lw%=\n\t"
                             "ds_write_b64 %[da], v[108:109] offset:16\n\t"
                             "ds_write_b64 %[da], v[110:111] offset:24\n\t"
-                            "ds_write_b64 %[d32], v[112:113]\n\t"
-                            "ds_write_b64 %[d32], v[114:115] offset:8\n\t"
+                            "ds_write_b64 %[tdst], v[112:113]\n\t"
+                            "ds_write_b64 %[tdst], v[114:115] offset:8\n\t"
                             "Lw%=:\n\t"
                             "s_mov_b64 exec, %[sv]\n\t"
                             "s_andn2_b64 %[todo], %[todo], %[ml]\n\t"
@@ -1144,8 +1154,8 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                               , [nr] "+s"(n_rounds)
 #endif
                             : [mA] "s"(mA_b), [m2] "s"(m2_b), [m3] "s"(m3_b), [m4] "s"(m4_b), [mS] "s"(mS_b), [mR] "s"(mR_b), [vl] "v"(lvl), [rsel] "v"(rsel), [rsh] "v"(rsh),
-                              [sa] "v"(sa), [s1] "v"(sa + a1), [s3] "v"(sa + o3), [s16] "v"(sa + M - 16u), [s32] "v"(sa + M - 32u),
-                              [da] "v"(da), [d1] "v"(da + a1), [d3] "v"(da + o3), [d16] "v"(da + M - 16u), [d32] "v"(da + M - 32u)
+                              [sa] "v"(sa), [tsrc] "v"(sa + M - 32u),
+                              [da] "v"(da), [tdst] "v"(da + M - 32u)
                             : "memory", "vcc", "scc", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113",
                               "v114", "v115", "v116", "v117");
                         RT(tm_asm);
@@ -1221,6 +1231,12 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                     }
                     RT(tm_asm);
                     if (mS) {
+                        // (this path is rare: its operands pass through an empty asm statement, or hipcc computes its predicates and
+                        //  addresses — some forty instructions — in the prologue of every batch)
+                        uint32_t M_s = M, off_s = off, dy_s = dy;
+                        asm volatile("" : "+v"(M_s), "+v"(off_s), "+v"(dy_s));
+                        const uint32_t M = M_s, off = off_s, dy = dy_s;
+                        const uint32_t sa = ring_a + ((dy - off) & kMask), da = ring_a + (dy & kMask);
                         const bool nowS = (mS >> lane) & 1ull;
                         const bool fits = nowS && (((dy - off) & kMask) + M <= (uint32_t)R) && ((dy & kMask) + M <= (uint32_t)R);   // neither range wraps
                         // (a) run-length matches (offset 1, 2 or 4): the pattern from one read, stores only.  Up to 64 bytes in
@@ -1419,6 +1435,10 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
 #endif
                     const bool old = sub == s_i && cls == 7u;
                     if (__ballot(old)) {
+                        // (a rare path: its operands pass through an empty asm statement, or its predicates are computed per batch)
+                        uint32_t M_o = M, off_o = off, dy_o = dy;
+                        asm volatile("" : "+v"(M_o), "+v"(off_o), "+v"(dy_o));
+                        const uint32_t M = M_o, off = off_o, dy = dy_o;
                         const uint32_t span = M < off ? M : off;
                         const uint32_t sy = dy - off;
                         if (__ballot(old && sy + span > fl)) { wait_resolved(ticket); flush_resolved(ticket); }
