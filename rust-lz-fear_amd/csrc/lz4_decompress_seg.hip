@@ -1426,13 +1426,9 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
 #if defined(LZF_SEG_DBG_SKIP) && LZF_SEG_DBG_SKIP == 3
                     fp = (oe + 15u) & ~15u;
 #endif
-#ifndef LZF_SEG_NOPF
                     prefetch_commit();
-#endif
                     fill_to((oe + 15u) & ~15u);
-#ifndef LZF_SEG_NOPF
                     prefetch_issue((oe + 15u) & ~15u);
-#endif
                     const bool old = sub == s_i && cls == 7u;
                     if (__ballot(old)) {
                         // (a rare path: its operands pass through an empty asm statement, or its predicates are computed per batch)
@@ -1461,9 +1457,6 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                 }
                 const uint32_t eg = oe & ~15u;
                 { const uint32_t k3 = ticket % 3u; if (k3 == 0u) endq0 = eg; else if (k3 == 1u) endq1 = eg; else endq2 = eg; }
-#ifdef LZF_SEG_VMW
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ring and the slot written; loads and stores to HBM stay in flight
                 ++ticket;
                 if (lane == 0u) flag_set(0, ticket);
