@@ -148,12 +148,18 @@ inline uint32_t seg_grid(uint32_t target, uint32_t n, uint32_t cap) {
 // stages: 1 plan, 2 parse, 3 seam, 4 tilesum, 5 scan, 6 records (+ levels), 8 resolve (all when upto >= 8)
 int seg_launch(const lzf::seg_ctx& c, uint32_t upto, hipStream_t st) {
     const uint32_t n = c.n_jobs;
+    // workgroups per launch of the chunk / tile kernels: about one chunk and a handful of tiles each — with 8 192 / 32 768 (each
+    // workgroup looping over a dozen chunks) the launches ended on their slowest loops: parse 4.3 -> 3.3 ms at 980 blocks, 1.02 -> 0.83 at 196
+    uint32_t tg_parse = 262144u, tg_tile = 524288u;
+#ifdef LZF_ANALYSIS      // LZF_SEG_GRID="parse,tiles": workgroups per launch of the chunk / tile kernels (A/B of the grid sizes)
+    { static const char* e = getenv("LZF_SEG_GRID"); if (e) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a && b) { tg_parse = a; tg_tile = b; } } }
+#endif
     LAUNCH(lzf::lzf_seg_plan_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, c);
-    if (upto >= 2) LAUNCH(lzf::lzf_seg_parse_kernel, dim3(seg_grid(8192u, n, c.maxch), n), dim3(64), 0, st, c);
+    if (upto >= 2) LAUNCH(lzf::lzf_seg_parse_kernel, dim3(seg_grid(tg_parse, n, c.maxch), n), dim3(64), 0, st, c);
     if (upto >= 3) LAUNCH(lzf::lzf_seg_seam_kernel, dim3(n), dim3(64), 0, st, c);
-    if (upto >= 4) LAUNCH(lzf::lzf_seg_tilesum_kernel, dim3(seg_grid(32768u, n, c.maxtile), n), dim3(64), 0, st, c);
+    if (upto >= 4) LAUNCH(lzf::lzf_seg_tilesum_kernel, dim3(seg_grid(tg_tile, n, c.maxtile), n), dim3(64), 0, st, c);
     if (upto >= 5) LAUNCH(lzf::lzf_seg_scan_kernel, dim3(n), dim3(64), 0, st, c);
-    if (upto >= 6) LAUNCH(lzf::lzf_seg_records_kernel, dim3(seg_grid(32768u, n, c.maxtile), n), dim3(64), 0, st, c);
+    if (upto >= 6) LAUNCH(lzf::lzf_seg_records_kernel, dim3(seg_grid(tg_tile, n, c.maxtile), n), dim3(64), 0, st, c);
     if (upto >= 8) {
         if (c.ring_bytes == 131072u) LAUNCH(lzf::lzf_seg_resolve_pair_kernel<131072>, dim3(n), dim3(128), 0, st, c);
         else if (c.ring_bytes == 65536u) LAUNCH(lzf::lzf_seg_resolve_pair_kernel<65536>, dim3(n), dim3(128), 0, st, c);
