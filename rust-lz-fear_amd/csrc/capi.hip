@@ -129,6 +129,8 @@ bool seg_alloc(SegScratch& s, const lzf_decompress_job* d_jobs, lzf_job_result* 
     const size_t o_to = take(sizeof(uint32_t) * (size_t)n * c.maxtile);
     const size_t o_bits = take(sizeof(uint32_t) * (size_t)n * c.maxch * lzf::kSegChunkWords);
     const size_t o_recs = take(sizeof(lzf::u32x4) * (size_t)c.rec_cap);
+    const size_t o_ord = take(sizeof(uint32_t) * (size_t)n);
+    const size_t o_len = take(sizeof(uint32_t) * (size_t)n);
     if (hipMallocAsync(&s.base, off, st) != hipSuccess) { (void)hipGetLastError(); s.base = nullptr; return false; }
     s.bytes = off;
     uint8_t* b = static_cast<uint8_t*>(s.base);
@@ -140,6 +142,10 @@ bool seg_alloc(SegScratch& s, const lzf_decompress_job* d_jobs, lzf_job_result* 
     c.tile_out = reinterpret_cast<uint32_t*>(b + o_to);
     c.bits = reinterpret_cast<uint32_t*>(b + o_bits);
     c.recs = reinterpret_cast<lzf::u32x4*>(b + o_recs);
+    c.n_cu = cu_count();
+    c.order = (n > c.n_cu && n <= 1024u) ? reinterpret_cast<uint32_t*>(b + o_ord) : nullptr;      // (one block per CU: nothing to balance)
+    c.by_len = (n >= 32u && n <= 1024u) ? reinterpret_cast<uint32_t*>(b + o_len) : nullptr;
+    c.rec_by_len = n >= 64u ? 1u : 0u;
     return true;
 }
 inline uint32_t seg_grid(uint32_t target, uint32_t n, uint32_t cap) {
@@ -154,11 +160,13 @@ int seg_launch(const lzf::seg_ctx& c, uint32_t upto, hipStream_t st) {
 #ifdef LZF_ANALYSIS      // LZF_SEG_GRID="parse,tiles": workgroups per launch of the chunk / tile kernels (A/B of the grid sizes)
     { static const char* e = getenv("LZF_SEG_GRID"); if (e) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a && b) { tg_parse = a; tg_tile = b; } } }
 #endif
+    if (c.by_len) LAUNCH(lzf::lzf_seg_by_len_kernel, dim3(1), dim3(1024), 0, st, c);
     LAUNCH(lzf::lzf_seg_plan_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, c);
     if (upto >= 2) LAUNCH(lzf::lzf_seg_parse_kernel, dim3(seg_grid(tg_parse, n, c.maxch), n), dim3(64), 0, st, c);
     if (upto >= 3) LAUNCH(lzf::lzf_seg_seam_kernel, dim3(n), dim3(64), 0, st, c);
     if (upto >= 4) LAUNCH(lzf::lzf_seg_tilesum_kernel, dim3(seg_grid(tg_tile, n, c.maxtile), n), dim3(64), 0, st, c);
     if (upto >= 5) LAUNCH(lzf::lzf_seg_scan_kernel, dim3(n), dim3(64), 0, st, c);
+    if (upto >= 6 && c.order) LAUNCH(lzf::lzf_seg_order_kernel, dim3(1), dim3(1024), 0, st, c);
     if (upto >= 6) LAUNCH(lzf::lzf_seg_records_kernel, dim3(seg_grid(tg_tile, n, c.maxtile), n), dim3(64), 0, st, c);
     if (upto >= 8) {
         if (c.ring_bytes == 131072u) LAUNCH(lzf::lzf_seg_resolve_pair_kernel<131072>, dim3(n), dim3(128), 0, st, c);

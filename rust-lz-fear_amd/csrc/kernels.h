@@ -127,10 +127,20 @@ struct seg_ctx {
     uint64_t rec_cap;
     uint32_t n_jobs, maxch, maxtile, max_in, min_in;
     uint32_t ring_bytes;         // LDS ring of the resolve stage (32 / 64 / 128 KiB): the records stage classes the sequences for it
+    uint32_t* order;             // [n_jobs]  resolve stage: workgroup -> job (null: identity); see lzf_seg_order_kernel
+    uint32_t n_cu;               // compute units of the device (the order deals the jobs out in rows of this many)
+    uint32_t* by_len;            // [n_jobs]  chunk / tile stages: grid row -> job, longest input first (null: identity)
+    uint32_t rec_by_len;         // the records stage follows by_len too (64 jobs and more; measured: below that its own order is quicker)
 };
 constexpr uint32_t kSegRegion = 256, kSegChunk = 64u * kSegRegion, kSegOverlap = 2048, kSegStride = kSegChunk - kSegOverlap;
 constexpr uint32_t kSegChunkWords = kSegChunk / 32u, kSegTile = 2048;
 __global__ void lzf_seg_plan_kernel(seg_ctx c);
+// batches of more than one block per CU: which workgroup of the resolve stage takes which job — the jobs ranked by their number of
+// sequences and dealt out in rows of n_cu, every other row reversed, so that the blocks that share a CU (workgroups k, k + n_cu,
+// k + 2 n_cu ... land on the same CU) are a slow one with fast ones: the launch ends with its slowest CU
+__global__ void lzf_seg_order_kernel(seg_ctx c);
+// the same batches: grid row -> job for the chunk / tile stages, longest input first (a launch ends with its last rows)
+__global__ void lzf_seg_by_len_kernel(seg_ctx c);
 __global__ void lzf_seg_parse_kernel(seg_ctx c);
 __global__ void lzf_seg_seam_kernel(seg_ctx c);
 __global__ void lzf_seg_tilesum_kernel(seg_ctx c);

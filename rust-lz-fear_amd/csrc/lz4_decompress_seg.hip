@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void lzf_seg_plan_kernel(seg_ctx c) {
 __global__ __launch_bounds__(64) void lzf_seg_parse_kernel(seg_ctx c) {
     __shared__ __attribute__((aligned(16))) uint8_t cbufs[16u + kCB + 16u];
     __shared__ __attribute__((aligned(16))) uint32_t rowsA[64u * 8u], rowsB[64u * 8u];
-    const uint32_t j = blockIdx.y;
+    const uint32_t j = c.by_len ? c.by_len[blockIdx.y] : blockIdx.y;
     const seg_job sj = c.st[j];
     if (!sj.eligible) return;
     const uint32_t lane = threadIdx.x & 63u;
@@ -634,7 +634,7 @@ __device__ __forceinline__ Tok tile_decode(const TileCtx& t, uint32_t p) {
 __global__ __launch_bounds__(64) void lzf_seg_tilesum_kernel(seg_ctx c) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kTileStage];
     __shared__ uint16_t list[kTileTokMax + 64u];
-    const uint32_t j = blockIdx.y;
+    const uint32_t j = c.by_len ? c.by_len[blockIdx.y] : blockIdx.y;
     const seg_job sj = c.st[j];
     if (!sj.eligible || sj.failed) return;
     const uint32_t lane = threadIdx.x & 63u;
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(64) void lzf_seg_records_kernel(seg_ctx c) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kTileStage];
     __shared__ uint16_t list[kTileTokMax + 64u];
     __shared__ uint32_t s_end[64], s_mo[64], s_lvl[64], s_pm[64];
-    const uint32_t j = blockIdx.y;
+    const uint32_t j = (c.by_len && c.rec_by_len) ? c.by_len[blockIdx.y] : blockIdx.y;
     const seg_job sj = c.st[j];
     if (!sj.eligible || sj.failed) return;
     const uint32_t lane = threadIdx.x & 63u;
@@ -852,6 +852,35 @@ __global__ __launch_bounds__(64) void lzf_seg_records_kernel(seg_ctx c) {
 }
 
 // =====================================================================================================================
+// order of the resolve stage's workgroups (kernels.h): one workgroup, n_jobs <= 1024
+// =====================================================================================================================
+__global__ __launch_bounds__(1024) void lzf_seg_by_len_kernel(seg_ctx c) {
+    __shared__ uint32_t cost[1024];
+    const uint32_t i = threadIdx.x, n = c.n_jobs;
+    if (i < n) { const uint64_t l = c.jobs[i].input_len; cost[i] = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l; }
+    __syncthreads();
+    if (i >= n) return;
+    const uint32_t mine = cost[i];
+    uint32_t r = 0;
+    for (uint32_t k = 0; k < n; ++k) { const uint32_t o = cost[k]; r += (o > mine || (o == mine && k < i)) ? 1u : 0u; }
+    c.by_len[r] = i;
+}
+__global__ __launch_bounds__(1024) void lzf_seg_order_kernel(seg_ctx c) {
+    __shared__ uint32_t cost[1024];
+    const uint32_t i = threadIdx.x, n = c.n_jobs;
+    if (i < n) { const seg_job s = c.st[i]; cost[i] = (s.eligible && !s.failed) ? s.ntok : 0u; }
+    __syncthreads();
+    if (i >= n) return;
+    const uint32_t mine = cost[i];
+    uint32_t r = 0;
+    for (uint32_t k = 0; k < n; ++k) { const uint32_t o = cost[k]; r += (o > mine || (o == mine && k < i)) ? 1u : 0u; }
+    const uint32_t ncu = c.n_cu ? c.n_cu : 256u;
+    const uint32_t row = r / ncu, col = r % ncu;
+    const uint32_t rowlen = n - row * ncu < ncu ? n - row * ncu : ncu;
+    c.order[row * ncu + ((row & 1u) ? rowlen - 1u - col : col)] = i;
+}
+
+// =====================================================================================================================
 // resolve: the dependent match copies of a block — a pair of wavefronts per block
 // =====================================================================================================================
 // Biased positions y = x + rb (rb = out & 15): y % 16 == 0 <=> out + x is 16-byte aligned; ring index = y & (R - 1).
@@ -873,8 +902,8 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[64 + R];
     uint8_t* const ring = lds_all + 64;
     uint32_t* const ctl = reinterpret_cast<uint32_t*>(lds_all);      // [0] staged tickets, [1] resolved tickets, [3] a wave gave up
-    const uint32_t j = blockIdx.x;
-    if (j >= c.n_jobs) return;
+    if (blockIdx.x >= c.n_jobs) return;
+    const uint32_t j = c.order ? c.order[blockIdx.x] : blockIdx.x;
     const seg_job sj = c.st[j];
     if (!sj.eligible || sj.failed) return;
     if (c.ring_bytes != (uint32_t)R) return;           // (the records were classed for another ring: leave the job to the pair kernel)
