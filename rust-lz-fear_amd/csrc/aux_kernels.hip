@@ -253,7 +253,52 @@ __global__ __launch_bounds__(1024) void lzf_order_by_cost_kernel(const lzf_compr
     }, perm, n);
 }
 
-// Decompress jobs: the work is the parse, i.e. proportional to the compressed bytes.
+// Decompress jobs: the work is the sequences.  Their number is estimated from three windows of the input (a token walk from an
+// arbitrary byte is in step with the block's token chain within about 1 KiB: tools/seq_stats.c): 1 KiB to fall in step, then the
+// tokens of the next 4 KiB counted, scaled to the input's length.  One wave per job; est[] in sequences.
+__global__ __launch_bounds__(64) void lzf_decompress_cost_kernel(const lzf_decompress_job* __restrict__ jobs, uint32_t n, uint32_t* __restrict__ est) {
+    constexpr uint32_t kSkip = 1024, kCount = 4096, kW = kSkip + kCount, kPad = 32;
+    __shared__ __attribute__((aligned(16))) uint8_t win[3][kW + kPad];
+    const uint32_t j = blockIdx.x;
+    if (j >= n) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const lzf_decompress_job job = jobs[j];
+    const uint32_t len = job.input_len > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)job.input_len;
+    if (!job.input || len < 3u * (kW + kPad)) { if (lane == 0u) est[j] = len >> 4; return; }      // (short inputs: a guess; they do not decide a launch's end)
+    cgu8* __restrict__ in = as_global(job.input);
+    const uint32_t third = (len - (kW + kPad)) / 3u;
+    for (uint32_t w = 0; w < 3u; ++w)
+        for (uint32_t i = lane * 16u; i < kW + kPad; i += 1024u) {
+            cgu8* g = in + w * third + i;                 // (16 bytes, any alignment)
+            u32x4 v; v[0] = ld4(g); v[1] = ld4(g + 4u); v[2] = ld4(g + 8u); v[3] = ld4(g + 12u);
+            *reinterpret_cast<u32x4*>(&win[w][i]) = v;
+        }
+    __syncthreads();
+    uint32_t cnt = 0, span = 0;
+    if (lane < 3u) {
+        const uint8_t* b = win[lane];
+        uint32_t p = 0, first = 0xFFFFFFFFu;
+        while (p < kW) {
+            if (p >= (lane ? kSkip : 0u)) { if (first == 0xFFFFFFFFu) first = p; ++cnt; }
+            const uint32_t tok = b[p];
+            uint32_t q = p + 1u, L = tok >> 4;
+            if (L == 15u) { uint32_t x; do { x = q < kW + kPad ? b[q] : 0u; ++q; L += x; } while (x == 255u && q < kW + kPad); }
+            q += L + 2u;
+            if ((tok & 15u) == 15u) { uint32_t x; do { x = q < kW + kPad ? b[q] : 0u; ++q; } while (x == 255u && q < kW + kPad); }
+            if (q <= p) break;
+            p = q;
+        }
+        span = first == 0xFFFFFFFFu ? 0u : (p < kW + kPad ? p : kW + kPad) - first;
+    }
+    cnt = __builtin_amdgcn_readlane(cnt, 0) + __builtin_amdgcn_readlane(cnt, 1) + __builtin_amdgcn_readlane(cnt, 2);
+    span = __builtin_amdgcn_readlane(span, 0) + __builtin_amdgcn_readlane(span, 1) + __builtin_amdgcn_readlane(span, 2);
+    if (lane == 0u) est[j] = span ? (uint32_t)(((uint64_t)len * cnt) / span) : len >> 4;
+}
+__global__ __launch_bounds__(1024) void lzf_order_by_estimate_kernel(const uint32_t* __restrict__ est, uint32_t* __restrict__ perm, uint32_t n) {
+    order_longest_first([&](uint32_t i) -> float { return (float)est[i]; }, perm, n);
+}
+
+// Decompress jobs by compressed bytes (the order when no scratch for the estimates is to be had).
 __global__ __launch_bounds__(1024) void lzf_order_by_input_len_kernel(const lzf_decompress_job* __restrict__ jobs,
                                                                       uint32_t* __restrict__ perm, uint32_t n) {
     order_longest_first([&](uint32_t i) -> float { return (float)jobs[i].input_len; }, perm, n);

@@ -283,8 +283,13 @@ int lzf_decompress_batch_sized(const lzf_decompress_job* d_jobs, lzf_job_result*
     AsyncScratch perm_owner; perm_owner.st = st;
     uint32_t*& perm = reinterpret_cast<uint32_t*&>(perm_owner.p);
     if (perm_ok && (use_order == 2u || (use_order == 1u && n_jobs > 8u * cu_count()))) {
-        if (hipMallocAsync(&perm_owner.p, sizeof(uint32_t) * (size_t)n_jobs, st) != hipSuccess) { (void)hipGetLastError(); perm_owner.p = nullptr; }   // (then: the caller's order)
-        if (perm) LAUNCH(lzf::lzf_order_by_input_len_kernel, dim3(1), dim3(1024), 0, st, d_jobs, perm, n_jobs);
+        // perm[n] + est[n]: the jobs by their estimated number of sequences, most first
+        if (hipMallocAsync(&perm_owner.p, 2u * sizeof(uint32_t) * (size_t)n_jobs, st) != hipSuccess) { (void)hipGetLastError(); perm_owner.p = nullptr; }   // (then: the caller's order)
+        if (perm) {
+            uint32_t* const est = perm + n_jobs;
+            LAUNCH(lzf::lzf_decompress_cost_kernel, dim3(n_jobs), dim3(64), 0, st, d_jobs, n_jobs, est);
+            LAUNCH(lzf::lzf_order_by_estimate_kernel, dim3(1), dim3(1024), 0, st, (const uint32_t*)est, perm, n_jobs);
+        }
     }
     const uint32_t* cperm = perm;
 #ifdef LZF_ANALYSIS
