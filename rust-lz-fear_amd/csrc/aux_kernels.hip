@@ -255,8 +255,9 @@ __global__ __launch_bounds__(1024) void lzf_order_by_cost_kernel(const lzf_compr
 
 // Decompress jobs: the work is the sequences.  Their number is estimated from three windows of the input (a token walk from an
 // arbitrary byte is in step with the block's token chain within about 1 KiB: tools/seq_stats.c): 1 KiB to fall in step, then the
-// tokens of the next 4 KiB counted, scaled to the input's length.  One wave per job; est[] in sequences.
-__global__ __launch_bounds__(64) void lzf_decompress_cost_kernel(const lzf_decompress_job* __restrict__ jobs, uint32_t n, uint32_t* __restrict__ est) {
+// tokens of the next 4 KiB counted, scaled to the input's length.  One wave per job; est[] = sequences + input_len >> len_shift (the
+// bytes cost too: staging, literals).
+__global__ __launch_bounds__(64) void lzf_decompress_cost_kernel(const lzf_decompress_job* __restrict__ jobs, uint32_t n, uint32_t* __restrict__ est, uint32_t len_shift) {
     constexpr uint32_t kSkip = 1024, kCount = 4096, kW = kSkip + kCount, kPad = 32;
     __shared__ __attribute__((aligned(16))) uint8_t win[3][kW + kPad];
     const uint32_t j = blockIdx.x;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_cost_kernel(const lzf_decom
     }
     cnt = __builtin_amdgcn_readlane(cnt, 0) + __builtin_amdgcn_readlane(cnt, 1) + __builtin_amdgcn_readlane(cnt, 2);
     span = __builtin_amdgcn_readlane(span, 0) + __builtin_amdgcn_readlane(span, 1) + __builtin_amdgcn_readlane(span, 2);
-    if (lane == 0u) est[j] = span ? (uint32_t)(((uint64_t)len * cnt) / span) : len >> 4;
+    if (lane == 0u) est[j] = (span ? (uint32_t)(((uint64_t)len * cnt) / span) : len >> 4) + (len_shift < 32u ? len >> len_shift : 0u);
 }
 __global__ __launch_bounds__(1024) void lzf_order_by_estimate_kernel(const uint32_t* __restrict__ est, uint32_t* __restrict__ perm, uint32_t n) {
     order_longest_first([&](uint32_t i) -> float { return (float)est[i]; }, perm, n);

@@ -167,7 +167,7 @@ extern template __global__ void lzf_compress_compact_kernel<true>(const lzf_comp
 __global__ void lzf_cost_probe_jobs_kernel(const lzf_compress_job* __restrict__ jobs, lzf_compress_job* __restrict__ probes, uint32_t n,
                                            uint32_t piece, uint32_t parts);
 __global__ void lzf_order_by_input_len_kernel(const lzf_decompress_job* __restrict__ jobs, uint32_t* __restrict__ perm, uint32_t n);
-__global__ void lzf_decompress_cost_kernel(const lzf_decompress_job* __restrict__ jobs, uint32_t n, uint32_t* __restrict__ est);
+__global__ void lzf_decompress_cost_kernel(const lzf_decompress_job* __restrict__ jobs, uint32_t n, uint32_t* __restrict__ est, uint32_t len_shift);
 __global__ void lzf_order_by_estimate_kernel(const uint32_t* __restrict__ est, uint32_t* __restrict__ perm, uint32_t n);
 __global__ void lzf_order_by_cost_kernel(const lzf_compress_job* __restrict__ jobs, const lzf_job_result* __restrict__ probe_results,
                                          uint32_t* __restrict__ perm, uint32_t n, uint32_t piece, uint32_t parts);
