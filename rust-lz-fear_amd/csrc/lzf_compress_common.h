@@ -1,12 +1,12 @@
 // lzf_compress_common.h — pieces shared by the compress kernels (skip schedule, bounded sink, LSIC coding).
 #pragma once
-#include "lzf_device.h"
+#include "lzf_simt.h"      // (lzf_device.h under hipcc; plain C++ stand-ins for the CPU emulation of the test suite)
 
 namespace lzf {
 
 // S(m) = sum of the first m advances of one literal run (mod.rs:174-175,225-231):
 // advance after probe j is 1 for j <= 65, then (62 + j) >> 6.
-__device__ __forceinline__ uint32_t sched_prefix(uint32_t m) {
+LZF_SIMT_FN uint32_t sched_prefix(uint32_t m) {
     if (m <= 66u) return m;
     const uint32_t r = m - 66u;
     const uint32_t full = r >> 6, rem = r & 63u;
@@ -27,9 +27,9 @@ struct Sink {
 };
 
 // LSIC tail length in bytes (mod.rs:243-260): 0 if v < 15 else (v-15)/255 + 1.
-__device__ __forceinline__ uint32_t lsic_len(uint32_t v) { return v < 15u ? 0u : (v - 15u) / 255u + 1u; }
+LZF_SIMT_FN uint32_t lsic_len(uint32_t v) { return v < 15u ? 0u : (v - 15u) / 255u + 1u; }
 
-__device__ __forceinline__ void lsic_store(gu8* dst, uint32_t v, uint32_t n, uint32_t lane) {
+LZF_SIMT_FN void lsic_store(gu8* dst, uint32_t v, uint32_t n, uint32_t lane) {
     // n = lsic_len(v) > 0: n-1 bytes of 0xFF then (v-15) % 255
     for (uint32_t i = lane; i < n; i += kWave) dst[i] = (i + 1u == n) ? (uint8_t)((v - 15u) % 255u) : (uint8_t)0xFF;
 }
@@ -38,7 +38,7 @@ __device__ __forceinline__ void lsic_store(gu8* dst, uint32_t v, uint32_t n, uin
 // Jobs the compact-table kernel (lz4_compress_compact.hip) takes instead of the general one: U32Table semantics with a
 // fresh table or a read-only template whose `offset` is 0 (every block the frame layer compresses in independent-
 // blocks mode, src/framed/compress.rs:220,265-270), positions below 2 GiB.
-__device__ __forceinline__ bool compress_job_is_compact(const lzf_compress_job& job) {
+LZF_SIMT_FN bool compress_job_is_compact(const lzf_compress_job& job) {
     if (job.table_kind != LZF_TABLE_U32 || job.input_len >= kMaxLen || job.cursor > job.input_len) return false;
     if (!job.table) return true;
     if (!(job.flags & LZF_CJOB_TABLE_READONLY)) return false;

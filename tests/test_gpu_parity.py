@@ -180,11 +180,12 @@ def test_every_decompress_kernel_generation(variant):
     assert "variant ok" in r.stdout
 
 
-@pytest.mark.parametrize("kernel", ["compact", "general", "ordered"])
+@pytest.mark.parametrize("kernel", ["rows", "compact", "general", "ordered"])
 def test_every_compress_kernel(kernel):
-    """Fresh-table U32 jobs through the compact-table kernel (default) and through the general kernel: same bytes as
-    the oracle, over inputs that cross several 64 KiB epochs, skip epochs inside one match and widen the batches.
-    "ordered": the cost probe + longest-first launch order that large batches get, forced on for this small one."""
+    """Fresh-table U32 jobs through the row-mapped kernel (four blocks per wavefront: the default), the one-block-per-wave
+    compact-table kernel and the general kernel: same bytes as the oracle, over inputs that cross several 64 KiB epochs,
+    skip epochs inside one match and widen the batches.
+    "ordered": the cost probe + longest-first queue order that large batches get, forced on for this small one."""
     import subprocess, sys
     env = _analysis_env(LZF_COMPRESS_KERNEL=kernel) if kernel != "ordered" else _analysis_env(LZF_COMPRESS_ORDER="always")
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "compress_variant_check.py")], env=env,
