@@ -20,8 +20,8 @@ LIB_PATH = os.environ.get("LZF_LIB_PATH") or os.path.join(PKG_DIR, "liblzfear_hi
 ANALYSIS_LIB_PATH = os.path.join(PKG_DIR, "liblzfear_hip_analysis.so")
 
 PRODUCT_HIP = ["capi.hip", "lz4_decompress_batched.hip", "lz4_decompress_paired.hip", "lz4_decompress_seg.hip", "lz4_compress.hip",
-               "lz4_compress_compact.hip", "lz4_compress_rows.hip", "aux_kernels.hip"]
-ANALYSIS_HIP = ["lz4_decompress.hip", "lz4_decompress_windowed.hip", "lz4_decompress_v6.hip"]
+               "lz4_compress_compact.hip", "aux_kernels.hip"]
+ANALYSIS_HIP = ["lz4_decompress.hip", "lz4_decompress_windowed.hip", "lz4_decompress_v6.hip", "lz4_compress_rows.hip"]
 CXX_SOURCES = ["frame.cpp", "host_staging.cpp"]
 HEADERS = ["kernels.h", "lzf_device.h", "lz4_decompress_batch_phase.inc", "lz4_decompress_parse_phase.inc",
            "lz4_decompress_copy3.inc",

@@ -220,53 +220,57 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
     // others to the general kernel; which is which is in the job array, i.e. in HBM, so both are launched (a wave of the
     // kernel that does not own a job reads the job and returns) unless the caller vouches for the batch with
     // LZF_KINDS_U32_FRESH_ONLY.
-    uint32_t use_compact = 1u, use_order = 1u, use_rows = 1u;
+    uint32_t use_compact = 1u, use_order = 1u, use_rows = 0u;
 #ifdef LZF_ANALYSIS
-    { static const uint32_t which = [] { const char* e = getenv("LZF_COMPRESS_KERNEL"); return !e ? 0u : !strcmp(e, "general") ? 1u : !strcmp(e, "compact") ? 2u : 0u; }();
+    // LZF_COMPRESS_KERNEL = general (everything on lzf_compress_wave_kernel) | rows (round 4's four-blocks-per-wavefront kernel,
+    // lz4_compress_rows.hip: measured slower than the compact kernel at every batch size, kept as a variant; profiles/r04_compress_rows.txt)
+    { static const uint32_t which = [] { const char* e = getenv("LZF_COMPRESS_KERNEL"); return !e ? 0u : !strcmp(e, "general") ? 1u : !strcmp(e, "rows") ? 2u : 0u; }();
       static const uint32_t order = analysis_order("LZF_COMPRESS_ORDER");
-      use_compact = which == 1u ? 0u : 1u; use_rows = which == 0u ? 1u : 0u; use_order = order; }
+      use_compact = which == 1u ? 0u : 1u; use_rows = which == 2u ? 1u : 0u; use_order = order; }
 #endif
     const bool fresh_only = use_compact && (table_kinds & LZF_KINDS_U32_FRESH_ONLY);
     uint32_t* perm = nullptr;
-    uint32_t* queue = nullptr;
     AsyncScratch scratch_owner; scratch_owner.st = st;
     void*& scratch = scratch_owner.p;
-    // The compact-table jobs run four to a wavefront on persistent waves (lz4_compress_rows.hip): 4 waves per CU, each row of a
-    // wave takes jobs from a queue until it is empty.  A batch that does not fill the rows of the chip spreads over more waves.
-    const uint32_t rows_waves = 4u * cu_count();
-    uint32_t rows_active = (n_jobs + rows_waves - 1u) / rows_waves;
-    if (rows_active > 4u) rows_active = 4u;
-    const uint32_t rows_grid = (n_jobs + rows_active - 1u) / rows_active < rows_waves ? (n_jobs + rows_active - 1u) / rows_active : rows_waves;
     // the cost of a compress job is not known from its size: probe (aux_kernels.hip), then longest first
-    const bool want_order = use_order && use_compact && (table_kinds & LZF_KINDS_U32) && (use_order == 2u || n_jobs > 16u * cu_count());
-    {
-        const uint32_t piece = 65536u, parts = 1u;      // one 64 KiB piece from the middle of each payload (more or smaller pieces order no better)
-        const size_t n_probes = want_order ? (size_t)n_jobs * parts : 0u;
-        const size_t probes_off = 256;                  // [queue][probe jobs][probe results][perm]
-        const size_t res_off = probes_off + align_up(sizeof(lzf_compress_job) * n_probes, 256);
-        const size_t perm_off = res_off + align_up(sizeof(lzf_job_result) * n_probes, 256);
-        // (the order and the queue are optimisations: without scratch memory the batch runs one block per wave in the caller's order)
+    const bool want_order = use_order && use_compact && (table_kinds & LZF_KINDS_U32) && (use_order == 2u || n_jobs > 18u * cu_count());
+    const uint32_t piece = 65536u, parts = 1u;      // one 64 KiB piece from the middle of each payload (more or smaller pieces order no better)
+    const size_t n_probes = want_order ? (size_t)n_jobs * parts : 0u;
+    const size_t probes_off = 256;                  // [queue of the rows variant][probe jobs][probe results][perm]
+    const size_t res_off = probes_off + align_up(sizeof(lzf_compress_job) * n_probes, 256);
+    const size_t perm_off = res_off + align_up(sizeof(lzf_job_result) * n_probes, 256);
+    if (want_order || use_rows) {
+        // (the order is an optimisation: without scratch memory the batch simply runs in the caller's order)
         if (hipMallocAsync(&scratch, perm_off + sizeof(uint32_t) * (want_order ? (size_t)n_jobs : 0u), st) != hipSuccess) { (void)hipGetLastError(); scratch = nullptr; }
-        if (scratch) {
-            queue = reinterpret_cast<uint32_t*>(scratch);
-            HIP_TRY(hipMemsetAsync(queue, 0, 256, st));
-        }
-        if (scratch && want_order) {
-            lzf_compress_job* probes = reinterpret_cast<lzf_compress_job*>(static_cast<uint8_t*>(scratch) + probes_off);
-            lzf_job_result* pres = reinterpret_cast<lzf_job_result*>(static_cast<uint8_t*>(scratch) + res_off);
-            perm = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(scratch) + perm_off);
-            LAUNCH(lzf::lzf_cost_probe_jobs_kernel, dim3((uint32_t)((n_probes + 255u) / 256u)), dim3(256), 0, st, d_jobs, probes, n_jobs, piece, parts);
-            LAUNCH(k_compact_dry, dim3((uint32_t)n_probes), dim3(64), 0, st, probes, pres, (uint32_t)n_probes, (const uint32_t*)nullptr, 0u);
-            LAUNCH(lzf::lzf_order_by_cost_kernel, dim3(1), dim3(1024), 0, st, d_jobs, pres, perm, n_jobs, piece, parts);
-        }
+    }
+    if (scratch && want_order) {
+        lzf_compress_job* probes = reinterpret_cast<lzf_compress_job*>(static_cast<uint8_t*>(scratch) + probes_off);
+        lzf_job_result* pres = reinterpret_cast<lzf_job_result*>(static_cast<uint8_t*>(scratch) + res_off);
+        perm = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(scratch) + perm_off);
+        LAUNCH(lzf::lzf_cost_probe_jobs_kernel, dim3((uint32_t)((n_probes + 255u) / 256u)), dim3(256), 0, st, d_jobs, probes, n_jobs, piece, parts);
+        LAUNCH(k_compact_dry, dim3((uint32_t)n_probes), dim3(64), 0, st, probes, pres, (uint32_t)n_probes, (const uint32_t*)nullptr, 0u);
+        LAUNCH(lzf::lzf_order_by_cost_kernel, dim3(1), dim3(1024), 0, st, d_jobs, pres, perm, n_jobs, piece, parts);
     }
     if (table_kinds & LZF_KINDS_U32) {
 #ifdef LZF_DBG_DRY_MAIN      // analysis: results[].reserved = probe batches + sequences of the whole job (no output)
         if (use_compact) LAUNCH(k_compact_dry, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, 0u);
 #else
-        if (use_compact && use_rows && queue)
-            LAUNCH(lzf::lzf_compress_rows_kernel, dim3(rows_grid), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, queue, rows_active, fresh_only ? 1u : 0u);
-        else if (use_compact) LAUNCH(k_compact, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, fresh_only ? 1u : 0u);
+        bool rows_done = false;
+#ifdef LZF_ANALYSIS
+        if (use_compact && use_rows && scratch) {
+            // four jobs per wavefront on persistent waves, 4 waves per CU; each row of a wave takes jobs from a queue until it is
+            // empty; a batch that does not fill the rows of the chip spreads over more waves
+            uint32_t* queue = reinterpret_cast<uint32_t*>(scratch);
+            HIP_TRY(hipMemsetAsync(queue, 0, 256, st));
+            const uint32_t rows_waves = 4u * cu_count();
+            uint32_t rows_active = (n_jobs + rows_waves - 1u) / rows_waves;
+            if (rows_active > 4u) rows_active = 4u;
+            const uint32_t need = (n_jobs + rows_active - 1u) / rows_active;
+            LAUNCH(lzf::lzf_compress_rows_kernel, dim3(need < rows_waves ? need : rows_waves), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, queue, rows_active, fresh_only ? 1u : 0u);
+            rows_done = true;
+        }
+#endif
+        if (use_compact && !rows_done) LAUNCH(k_compact, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, fresh_only ? 1u : 0u);
 #endif
         if (!fresh_only) LAUNCH(k_general_u32, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, use_compact, (const uint32_t*)perm);
     }

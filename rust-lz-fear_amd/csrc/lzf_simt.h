@@ -30,11 +30,43 @@ struct SimtGpu {
     LZF_SIMT_FN void lds_min32(bool p, uint32_t w, uint32_t v) const { if (p) atomicMin(&lds[w], v); }
     // mem = (mem & ~mask) | val
     LZF_SIMT_FN void lds_mskor32(bool p, uint32_t w, uint32_t mask, uint32_t val) const { if (p) lds_mskor32_raw(lds_a + 4u * w, mask, val); }
+    // the same without a predicate: a lane with nothing to do aims at a scratch word of its own instead of leaving the instruction
+    // (no exec-mask bookkeeping around the access)
+    LZF_SIMT_FN uint32_t lds_rd32u(uint32_t w) const { return lds[w]; }
+    LZF_SIMT_FN void lds_wr32u(uint32_t w, uint32_t v) const { lds[w] = v; }
+    LZF_SIMT_FN void lds_min32u(uint32_t w, uint32_t v) const { atomicMin(&lds[w], v); }
+    LZF_SIMT_FN void lds_mskor32u(uint32_t w, uint32_t mask, uint32_t val) const { lds_mskor32_raw(lds_a + 4u * w, mask, val); }
+    // 16 aligned bytes to LDS words w .. w + 3
+    LZF_SIMT_FN void lds_wr128(bool p, uint32_t w, u32x4 v) const { if (p) *reinterpret_cast<u32x4*>(&lds[w]) = v; }
+    // three 8-byte reads at ANY byte offset of the LDS array (gfx950 executes misaligned DS accesses; hipcc would split them into
+    // bytes, hence the asm — which also waits for its own data, the compiler does not count asm memory operations)
+    LZF_SIMT_FN void lds_rd64b3(bool p, uint32_t b0, uint32_t b1, uint32_t b2, uint64_t& v0, uint64_t& v1, uint64_t& v2) const {
+        if (p) {
+            uint64_t r0, r1, r2;
+            asm volatile("ds_read_b64 %0, %3\n\tds_read_b64 %1, %4\n\tds_read_b64 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(r0), "=&v"(r1), "=&v"(r2) : "v"(lds_a + b0), "v"(lds_a + b1), "v"(lds_a + b2) : "memory");
+            v0 = r0; v1 = r1; v2 = r2;
+        }
+    }
     LZF_SIMT_FN uint32_t atomic_inc(uint32_t* q) const { return atomicAdd(q, 1u); }
     LZF_SIMT_FN uint64_t clock() const { return (uint64_t)clock64(); }
+    LZF_SIMT_FN void keep(uint32_t v) const { asm volatile("" ::"v"(v)); }      // the value counts as used (a load made only to warm the caches)
+    LZF_SIMT_FN uint64_t clock_fenced() const { __builtin_amdgcn_s_waitcnt(0); return (uint64_t)clock64(); }      // (debug timers) every outstanding access first
     static LZF_SIMT_FN void lds_mskor32_raw(uint32_t a, uint32_t mask, uint32_t val) { asm volatile("ds_mskor_b32 %0, %1, %2" ::"v"(a), "v"(mask), "v"(val) : "memory"); }
 };
-LZF_SIMT_FN uint32_t simt_mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }      // both below 2^24: a full-rate multiply
+// mod.rs:41-51: v = 8 bytes LE, ((v << 24) * 889523592379) >> 52 — bits 28..39 of the low 40 bits of v * K.  With v = xl + (xh << 32),
+// K = 0x1BBCDCBB + (0xCF << 32): v * K mod 2^40 = xl * 0x1BBCDCBB + ((xl * 0xCF + xh * 0xBB) mod 2^8 << 32): one 32 x 32 -> 64
+// multiply-add and two 24-bit multiplies (full rate) instead of the three quarter-rate multiplies of a 64-bit product.  hipcc
+// folds the C form of this back into the 64-bit multiply, hence the asm.
+LZF_SIMT_FN uint32_t simt_hash5(uint64_t v8) {
+    const uint32_t xl = (uint32_t)v8, xh = (uint32_t)(v8 >> 32);
+    uint32_t t, u; uint64_t p;
+    asm("v_and_b32 %0, 0xff, %1\n\tv_mul_u32_u24 %0, 0xcf, %0" : "=v"(t) : "v"(xl));
+    asm("v_and_b32 %0, 0xff, %1\n\tv_mul_u32_u24 %0, 0xbb, %0" : "=v"(u) : "v"(xh));
+    asm("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(p) : "v"(xl), "s"(0x1BBCDCBBu) : "vcc");
+    const uint32_t hi = (uint32_t)(p >> 32) + t + u;
+    return ((hi & 0xFFu) << 4) | ((uint32_t)p >> 28);
+}
 LZF_SIMT_FN uint32_t simt_ctz32(uint32_t v) { return (uint32_t)__builtin_ctz(v); }
 LZF_SIMT_FN uint32_t simt_ctz64(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
 LZF_SIMT_FN uint32_t simt_clz64(uint64_t v) { return (uint32_t)__builtin_clzll(v); }
@@ -57,7 +89,7 @@ template <typename T> static inline gu8* as_global(T* p) { return (gu8*)p; }
 static inline uint64_t ld8(cgu8* p) { uint64_t v; memcpy(&v, p, 8); return v; }
 static inline u32x4 ld16(cgu8* p) { u32x4 v; memcpy(&v, p, 16); return v; }
 static inline void st16(gu8* p, u32x4 v) { memcpy(p, &v, 16); }
-static inline uint32_t simt_mul24(uint32_t a, uint32_t b) { return a * b; }
+static inline uint32_t simt_hash5(uint64_t v8) { return (uint32_t)(((v8 << 24) * 889523592379ull) >> 52); }      // mod.rs:41-51
 static inline uint32_t simt_ctz32(uint32_t v) { return (uint32_t)__builtin_ctz(v); }
 static inline uint32_t simt_ctz64(uint64_t v) { return (uint32_t)__builtin_ctzll(v); }
 static inline uint32_t simt_clz64(uint64_t v) { return (uint32_t)__builtin_clzll(v); }
@@ -96,8 +128,19 @@ struct SimtEmu {
     void lds_wr32(bool p, uint32_t i, uint32_t v) const { sync(); if (p) w->lds[i] = v; }
     void lds_min32(bool p, uint32_t i, uint32_t v) const { sync(); if (p && v < w->lds[i]) w->lds[i] = v; }
     void lds_mskor32(bool p, uint32_t i, uint32_t mask, uint32_t val) const { sync(); if (p) w->lds[i] = (w->lds[i] & ~mask) | val; }
+    uint32_t lds_rd32u(uint32_t i) const { return lds_rd32(true, i); }
+    void lds_wr32u(uint32_t i, uint32_t v) const { lds_wr32(true, i, v); }
+    void lds_min32u(uint32_t i, uint32_t v) const { lds_min32(true, i, v); }
+    void lds_mskor32u(uint32_t i, uint32_t mask, uint32_t val) const { lds_mskor32(true, i, mask, val); }
+    void lds_wr128(bool p, uint32_t i, u32x4 v) const { sync(); if (p) memcpy(&w->lds[i], &v, 16); }
+    void lds_rd64b3(bool p, uint32_t b0, uint32_t b1, uint32_t b2, uint64_t& v0, uint64_t& v1, uint64_t& v2) const {
+        sync();
+        if (p) { const uint8_t* l = (const uint8_t*)w->lds; memcpy(&v0, l + b0, 8); memcpy(&v1, l + b1, 8); memcpy(&v2, l + b2, 8); }
+    }
     uint32_t atomic_inc(uint32_t* q) const { return (*q)++; }
     uint64_t clock() const { return 0; }
+    void keep(uint32_t) const {}
+    uint64_t clock_fenced() const { return 0; }
 };
 }  // namespace lzf
 #endif

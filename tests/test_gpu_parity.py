@@ -182,8 +182,9 @@ def test_every_decompress_kernel_generation(variant):
 
 @pytest.mark.parametrize("kernel", ["rows", "compact", "general", "ordered"])
 def test_every_compress_kernel(kernel):
-    """Fresh-table U32 jobs through the row-mapped kernel (four blocks per wavefront: the default), the one-block-per-wave
-    compact-table kernel and the general kernel: same bytes as the oracle, over inputs that cross several 64 KiB epochs,
+    """Fresh-table U32 jobs through the compact-table kernel (default), the general kernel and round 4's row-mapped variant
+    (four blocks per wavefront, persistent waves, a job queue — the same source the CPU suite runs under the lock-step
+    emulator, tests/test_emu_compress_rows.py): same bytes as the oracle, over inputs that cross several 64 KiB epochs,
     skip epochs inside one match and widen the batches.
     "ordered": the cost probe + longest-first queue order that large batches get, forced on for this small one."""
     import subprocess, sys

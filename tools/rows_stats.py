@@ -22,13 +22,18 @@ for it in range(2):
     dt = time.time() - t
 print(f"jobs {m} time {dt*1e3:.1f} ms  {len(data)*copies/dt/2**30:.2f} GiB/s")
 res = device.results_to_host(d_res, m)
-heads = d_out.view(m, BS)[:, :24].cpu().numpy().view(np.uint32).reshape(m, 6).astype(np.float64)
+raw = d_out.view(m, BS)[:, :56].cpu().numpy().view(np.uint32).reshape(m, 14).astype(np.float64)
+heads, secs = raw[:, :6], raw[:, 6:]
 ok = res['status'] == 0
 print("blk   iters  rare  batches direct slow  Mcyc  cyc/iter  cyc/batch  direct/batches")
 for b in list(range(0, min(n, 51), 3)):
     it, rare, bat, dr, sl, cyc = heads[b]
     cyc *= 64
     print("%3d %7d %6d %7d %6d %5d %6.1f %8.0f %9.0f %6.2f  st %d" % (b, it, rare, bat, dr, sl, cyc / 1e6, cyc / max(it, 1), cyc / max(bat, 1), dr / max(bat, 1), res['status'][b]))
+names = ["rare+prologue", "input wait+insert", "hash+table+tag", "cut+cand+gather", "commit+eval+bcast", "ext1", "emit+next loads", "loop top"]
+for b in (0, 3, 18, 33):
+    if b < m and ok[b]:
+        print("block %d: cycles per batch by section (fenced timers): " % b + ", ".join("%s %.0f" % (nm, secs[b][k] * 64 / max(heads[b][2], 1)) for k, nm in enumerate(names)))
 h = heads[ok]
 tot = h.sum(axis=0)
 print("all ok blocks: iters %.0f rare %.0f batches %.0f direct %.0f slow %.0f  cycles/iter %.0f" % (tot[0], tot[1], tot[2], tot[3], tot[4], tot[5] * 64 / tot[0]))
