@@ -2,7 +2,10 @@
 """bench.py — GiB/s of the LZ4 raw-block hot path on MI355X (BASELINE.json metric).
 
   python bench.py --gpus N --steps K --warmup W [--workload silesia|config4]
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 without a launcher (no WORLD_SIZE in the environment): the script starts itself under
+  `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>` — one rank per GPU
+  over RCCL — and rank 0 prints the line.  Under a launcher (the driver's torch.distributed.run) it reads RANK / LOCAL_RANK /
+  WORLD_SIZE / MASTER_* as given.
 
 --workload silesia (default; BASELINE.json configs[1], compress of the same blocks = configs[2] under "compress"):
   the Silesia stand-in `silesia_mix` (211 938 580 B, rust-lz-fear_amd/synth.py) cut into 4 MiB independent blocks and tiled
@@ -186,6 +189,38 @@ def timed_launches(torch, fn, steps):
     return evs
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: the same command line under torch.distributed.run, one rank per GPU."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"[bench] --gpus {n} without a launcher: " + " ".join(cmd))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def launch_check(args, rank, world):
+    """The launcher path without a GPU: gloo group, every rank's block range of the config4 stream gathered, rank 0 prints them."""
+    import torch
+    import torch.distributed as dist
+    from rust_lz_fear_amd.dist import shard_range
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    lo, hi = shard_range(args.blocks, rank, world)
+    mine = torch.tensor([rank, lo, hi], dtype=torch.int64)
+    allr = [torch.zeros(3, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(allr, mine)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "world": dist.get_world_size(), "blocks": args.blocks,
+                          "ranges": [[int(x) for x in t.tolist()] for t in allr]}), flush=True)
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,12 +235,20 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-config4", action="store_true", help="silesia workload: skip the strong-scaled configs[3] leg of the line")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="no GPU work: every rank joins a gloo group, the ranks agree on their block ranges, rank 0 prints them (test of the self-launch path)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: become one (the ranks inherit stdout: rank 0's JSON line is this process's output)
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if args.launch_check:
+        return launch_check(args, rank, world)
 
     t0 = time.time()
     bases = None
