@@ -106,6 +106,11 @@ inline uint32_t seg_nch_host(uint32_t len) { return len <= lzf::kSegChunk ? 1u :
 bool seg_alloc(SegScratch& s, const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n, uint32_t min_in, hipStream_t st, uint64_t max_in_hint = ~0ull) {
     lzf::seg_ctx& c = s.ctx;
     c.jobs = d_jobs; c.results = d_results; c.n_jobs = n;
+#ifdef LZF_ANALYSIS      // LZF_SEG_FORCE=noscratch | stager | resolver: the pipeline's fall-backs, forced (tests/test_gpu_parity.py)
+    { static const uint32_t force = [] { const char* e = getenv("LZF_SEG_FORCE"); return !e ? 0u : !strcmp(e, "stager") ? 1u : !strcmp(e, "resolver") ? 2u : !strcmp(e, "noscratch") ? 3u : 0u; }();
+      if (force == 3u) return false;
+      c.dbg_force = force; }
+#endif
     // (a caller that knows an upper bound of its jobs' input sizes gets scratch sized for it: the job array is in HBM, the host cannot look)
     const uint32_t max_in = max_in_hint < kSegMaxIn ? (uint32_t)(max_in_hint < lzf::kSegChunk ? lzf::kSegChunk : max_in_hint) : kSegMaxIn;
     c.max_in = max_in; c.min_in = min_in;

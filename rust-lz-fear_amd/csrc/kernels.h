@@ -131,6 +131,7 @@ struct seg_ctx {
     uint32_t n_cu;               // compute units of the device (the order deals the jobs out in rows of this many)
     uint32_t* by_len;            // [n_jobs]  chunk / tile stages: grid row -> job, longest input first (null: identity)
     uint32_t rec_by_len;         // the records stage follows by_len too (64 jobs and more; measured: below that its own order is quicker)
+    uint32_t dbg_force;          // analysis library only (LZF_SEG_FORCE): 1 = stagers of odd jobs give up, 2 = resolvers of odd jobs give up
 };
 constexpr uint32_t kSegRegion = 256, kSegChunk = 64u * kSegRegion, kSegOverlap = 2048, kSegStride = kSegChunk - kSegOverlap;
 constexpr uint32_t kSegChunkWords = kSegChunk / 32u, kSegTile = 2048;

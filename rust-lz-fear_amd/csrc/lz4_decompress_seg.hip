@@ -1011,6 +1011,9 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
 #endif
             bool gave_up = false;
             for (uint32_t s_i = 0; s_i < nsub; ++s_i, ++t) {
+#ifdef LZF_ANALYSIS      // LZF_SEG_FORCE=resolver: the resolver of every odd job gives up at its third ticket (test of the hand-over)
+                if (c.dbg_force == 2u && (j & 1u) && t >= 2u) { if (lane == 0u) flag_set(3, 1u); gave_up = true; break; }
+#endif
                 // ---- wait for the stager's ticket
                 if (s_i) {
                     RT(tm_setup);
@@ -1399,6 +1402,9 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
         if (n) { rA = recs[lane < n ? lane : n - 1u]; rB = recs[64u + lane < n ? 64u + lane : n - 1u]; }
         uint32_t prev_end = rb;                          // biased end of the previous sequence
         for (uint32_t i0 = 0; i0 < n && !gave_up; i0 += 64u) {
+#ifdef LZF_ANALYSIS      // LZF_SEG_FORCE=stager: the stager of every odd job gives up at its third batch
+            if (c.dbg_force == 1u && (j & 1u) && i0 >= 128u) { gave_up = true; if (lane == 0u) flag_set(3, 1u); break; }
+#endif
             const uint32_t nb = n - i0 < 64u ? n - i0 : 64u;
             const u32x4 r = rA;
             const uint32_t M = lane < nb ? r[0] : 0u, dy = r[1], off = r[3];
@@ -1493,6 +1499,9 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
             }
         }
         wait_resolved(ticket);
+        // A pair that gave up — this wave's bounded wait, the resolver's (ctl[3]), records this stage does not handle — leaves the
+        // job alone: no result, done stays 0, and the pair kernel launched behind this one decodes the block from its first byte.
+        if (gave_up || flag_get(3) != 0u) return;
 #if !(defined(LZF_SEG_DBG_SKIP) && LZF_SEG_DBG_SKIP == 3)
         flush_resolved(ticket);
         flush_range(fl, total + rb);

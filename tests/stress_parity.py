@@ -38,13 +38,11 @@ def make_input(rng, max_len):
     return b"".join(parts)[:target]
 
 
-def main():
-    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-    rng = np.random.default_rng(seed)
+def one_round(rng, r, sizes=(200, 5000, 70000, 400000, 1500000), n_inputs=24):
+    """One round of the stress: returns (inputs checked, damaged blocks checked); raises AssertionError on any difference."""
     n_in = n_bad = 0
-    for r in range(rounds):
-        data = [make_input(rng, int(rng.choice([200, 5000, 70000, 400000, 1500000]))) for _ in range(24)]
+    if True:
+        data = [make_input(rng, int(rng.choice(list(sizes)))) for _ in range(n_inputs)]
         # ---- compress, U32 fresh table
         res = ffi.compress_blocks_host([dict(input=d, out_cap=len(d) + len(d) // 200 + 64) for d in data])
         comps = []
@@ -83,6 +81,17 @@ def main():
             assert rc == erc and (rc != 0 or out == eout), ("damaged", r)
             n_bad += 1
         n_in += len(data)
+    return n_in, n_bad
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    n_in = n_bad = 0
+    for r in range(rounds):
+        a, b = one_round(rng, r)
+        n_in += a; n_bad += b
         print(f"round {r}: ok ({n_in} inputs, {n_bad} damaged blocks so far)", flush=True)
     print("stress ok")
 

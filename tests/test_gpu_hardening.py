@@ -1,0 +1,108 @@
+"""Hardening of the default decompress path at its real sizes (round 4): a time-boxed seeded stress through the PRODUCT dispatch,
+damaged 4 MiB blocks inside batches of 300 and 700 jobs (the 64 / 32 KiB-ring variants of the segmented pipeline and its device-side
+job orders), and the pipeline's fall-backs forced.  Everything is compared with the oracle: statuses always, bytes whenever Ok
+(reference behaviour: src/raw/decompress.rs:61-75,:82-89)."""
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+import oracle_ffi as o
+import rust_lz_fear_amd  # noqa: F401
+from rust_lz_fear_amd import ffi, synth
+
+pytestmark = pytest.mark.gpu
+BS = 4 << 20
+
+
+def test_seeded_stress_through_the_product_dispatch_60s():
+    """tests/stress_parity.py's rounds (random pieces of every generator, zero / motif runs across several 64 KiB epochs, copies at
+    random distances; compress U32 / U16 / cursor > 0 / tight caps == oracle, decompress == input, randomly damaged blocks ==
+    oracle's status and bytes) for 60 seconds, at least two rounds, with a fixed seed — through lzf_compress_batch /
+    lzf_decompress_batch of the product library, i.e. the segmented pipeline for every block of 64 KiB and more."""
+    import stress_parity
+    rng = np.random.default_rng(20260929)
+    t0 = time.time()
+    n_in = n_bad = rounds = 0
+    while rounds < 2 or time.time() - t0 < 60.0:
+        # (every fourth round with inputs of up to 4 MiB: full-size blocks through every stage of the pipeline)
+        sizes = (200, 5000, 70000, 400000, 1500000, 4 << 20) if rounds % 4 == 3 else (200, 5000, 70000, 400000, 1500000)
+        a, b = stress_parity.one_round(rng, rounds, sizes=sizes)
+        n_in += a; n_bad += b; rounds += 1
+    assert n_in >= 48 and n_bad >= 10
+    print(f"stress: {rounds} rounds, {n_in} inputs, {n_bad} damaged blocks in {time.time() - t0:.0f} s")
+
+
+def _damage(rng, c, kind):
+    b = bytearray(c)
+    if kind == 0:                                            # a few flipped bytes
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(0, len(b)))] ^= int(rng.integers(1, 256))
+    elif kind == 1:                                          # truncated
+        del b[int(rng.integers(len(b) // 3, len(b))):]
+    elif kind == 2:                                          # garbage tail
+        k = int(rng.integers(len(b) // 2, len(b)))
+        b[k:] = rng.integers(0, 256, len(b) - k, dtype=np.uint8).tobytes()
+    else:                                                    # a flipped byte in the first token region + truncation
+        b[int(rng.integers(0, 64))] ^= 0xFF
+        del b[int(rng.integers(len(b) // 2, len(b))):]
+    return bytes(b)
+
+
+@pytest.mark.parametrize("n_jobs", [300, 700])
+def test_damaged_4mib_blocks_inside_mid_size_batches(n_jobs):
+    """Batches of 300 and 700 jobs of 4 MiB blocks (more than one and more than two blocks per CU: the 64 KiB and the 32 KiB ring of
+    the resolve stage, the ranked job orders of the chunk / tile / resolve stages), a tenth of them damaged — flipped bytes,
+    truncation, a garbage tail: every status equals the oracle's (decompress.rs:61-75,:82-89) and every Ok job's bytes too; the good
+    blocks come back as their originals."""
+    rng = np.random.default_rng(1000 + n_jobs)
+    raws = [synth.silesia_mix(k * BS, (k + 1) * BS).tobytes() for k in (0, 3, 9, 17, 26, 31, 38, 44)]
+    comps = [o.compress2(d)[1] for d in raws]
+    assert all(len(c) >= 65536 for c in comps)
+    n_bad = n_jobs // 10
+    bad_at = set(int(x) for x in rng.choice(n_jobs, n_bad, replace=False))
+    items, exp, which = [], [], []
+    for i in range(n_jobs):
+        k = i % len(raws)
+        if i in bad_at:
+            m = _damage(rng, comps[k], int(rng.integers(0, 4)))
+            cap = BS + len(m) + 64                                            # limit + C reproduces every outcome
+            items.append(dict(input=m, limit=BS, out_cap=cap)); exp.append(o.decompress_raw(m, limit=BS, cap=cap)); which.append(-1)
+        else:
+            items.append(dict(input=comps[k], limit=BS, out_cap=BS + len(comps[k]) + 64)); exp.append(None); which.append(k)
+    res = ffi.decompress_blocks_host(items)
+    launch = ffi.lib().lzf_last_decompress_launch().decode()
+    assert launch.startswith("segmented"), launch
+    ring = "65536" if n_jobs <= 2 * 256 else "32768"
+    assert ring in launch or "131072" in launch, launch                      # (a device with more CUs picks a larger ring)
+    kinds = set()
+    for i, (rc, out) in enumerate(res):
+        if which[i] >= 0:
+            assert rc == 0 and out == raws[which[i]], i
+        else:
+            erc, eout = exp[i]
+            assert rc == erc, (i, rc, erc)
+            kinds.add(rc)
+            if rc == 0:
+                assert out == eout, i
+    assert len(kinds) >= 2, kinds                                              # more than one error kind was exercised
+
+
+def _analysis_env(**kw):
+    from rust_lz_fear_amd import build
+    return dict(os.environ, LZF_LIB_PATH=build.build_analysis_library(), **kw)
+
+
+@pytest.mark.parametrize("force", ["noscratch", "stager", "resolver"])
+def test_segmented_pipeline_fallbacks_forced(force):
+    """No scratch memory (seg_alloc fails -> the pair kernel decodes the whole batch) and a pair that gives up (what an expired
+    bounded wait does; here: the stager / the resolver of every odd job, in its third batch): the job is not reported by the
+    pipeline, the pair kernel launched behind it decodes the block from its first byte — oracle-identical results.  (ADVICE r3:
+    a job that gave up used to be reported Ok with a partly resolved block.)"""
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "seg_force_check.py")], env=_analysis_env(LZF_SEG_FORCE=force),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "force ok" in r.stdout
