@@ -46,14 +46,28 @@ int ensure_device() {
     return n;
 }
 
-uint32_t cu_count() {
-    static const uint32_t n = [] {
+// The geometry every dispatch threshold below is derived from: compute units and LDS bytes per CU of the current device, as the
+// runtime reports them (MI355X: 256 and 160 KiB).  Nothing in this file assumes those two numbers.
+struct Geometry { uint32_t cu, lds; };
+const Geometry& geometry() {
+    static const Geometry g = [] {
+        Geometry r{256u, 160u * 1024u};
         hipDeviceProp_t p; int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&p, dev) != hipSuccess) return 256u;
-        return (uint32_t)p.multiProcessorCount;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) {
+            r.cu = (uint32_t)p.multiProcessorCount;
+            if (p.maxSharedMemoryPerMultiProcessor >= 64u * 1024u) r.lds = (uint32_t)p.maxSharedMemoryPerMultiProcessor;
+        }
+        (void)hipGetLastError();
+#ifdef LZF_ANALYSIS      // LZF_FAKE_CU=n: dispatch as if the device had n compute units (test of the derived thresholds on one device)
+        if (const char* e = getenv("LZF_FAKE_CU")) { const long v = atol(e); if (v >= 1 && v <= 4096) r.cu = (uint32_t)v; }
+#endif
+        return r;
     }();
-    return n;
+    return g;
 }
+uint32_t cu_count() { return geometry().cu; }
+// workgroups of `lds_bytes` of LDS each that one CU holds
+uint32_t per_cu(uint32_t lds_bytes) { const uint32_t n = geometry().lds / lds_bytes; return n ? n : 1u; }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -92,7 +106,16 @@ constexpr auto k_general_u16 = lzf::lzf_compress_wave_kernel<LZF_TABLE_U16>;
 // ---- the segmented pipeline (lz4_decompress_seg.hip): geometry, scratch, launches ------------------------------------
 constexpr uint32_t kSegMaxIn = 4u * 1024u * 1024u + 32u * 1024u;     // a 4 MiB block at LZ4's worst case, rounded up
 constexpr uint32_t kSegMinIn = 64u * 1024u;                          // smaller blocks are done sooner by one workgroup
-constexpr uint32_t kSegMaxJobs = 1024;                               // four blocks per CU (32 KiB rings): what the LDS of 256 CUs holds at once; at 980 blocks 19.0 ms against 23.5 for the pair kernel
+// LDS of one workgroup of the resolve stage: its ring + flags, tickets and slack (lz4_decompress_seg.hip).  The pipeline takes
+// batches of up to one block per 32 KiB ring the chip's LDS holds (MI355X: 4 per CU = 1 024 blocks; at 980 blocks 18.2 ms against 23.5
+// for the pair kernel) and gives a block the largest ring that still leaves every block of the batch resident at once.
+constexpr uint32_t kSegRingSlack = 8u * 1024u;
+inline uint32_t seg_blocks_per_cu(uint32_t ring) { return per_cu(ring + kSegRingSlack); }
+inline uint32_t seg_max_jobs() { return seg_blocks_per_cu(32768u) * cu_count(); }
+inline uint32_t seg_ring_for(uint32_t n) {
+    return n <= seg_blocks_per_cu(131072u) * cu_count() && geometry().lds >= 131072u + kSegRingSlack ? 131072u
+         : n <= seg_blocks_per_cu(65536u) * cu_count() && geometry().lds >= 65536u + kSegRingSlack ? 65536u : 32768u;
+}
 constexpr uint64_t kSegRecsPerJob = 448u * 1024u;                    // arena: records per job on average (16 bytes each)
 
 struct SegScratch {
@@ -119,7 +142,7 @@ bool seg_alloc(SegScratch& s, const lzf_decompress_job* d_jobs, lzf_job_result* 
     { const uint64_t per_job = (uint64_t)max_in / 3u + 192u; c.rec_cap = (uint64_t)n * (per_job < kSegRecsPerJob ? per_job : kSegRecsPerJob); }
     // the ring of a block: 128 KiB holds every distance LZ4 can express (no read-backs from HBM) while a CU has one block,
     // 64 / 32 KiB with read-backs for the oldest few per cent of the sources beyond that
-    c.ring_bytes = n <= cu_count() ? 131072u : n <= 2u * cu_count() ? 65536u : 32768u;
+    c.ring_bytes = seg_ring_for(n);
 #ifdef LZF_ANALYSIS      // LZF_SEG_RING=32768|65536|131072: a ring size whatever the batch (one block per CU with the small rings: the stager's share)
     { static const uint32_t ring = [] { const char* e = getenv("LZF_SEG_RING"); return e ? (uint32_t)atol(e) : 0u; }();
       if (ring == 32768u || ring == 65536u || ring == 131072u) c.ring_bytes = ring; }
@@ -148,9 +171,9 @@ bool seg_alloc(SegScratch& s, const lzf_decompress_job* d_jobs, lzf_job_result* 
     c.bits = reinterpret_cast<uint32_t*>(b + o_bits);
     c.recs = reinterpret_cast<lzf::u32x4*>(b + o_recs);
     c.n_cu = cu_count();
-    c.order = (n > c.n_cu && n <= 1024u) ? reinterpret_cast<uint32_t*>(b + o_ord) : nullptr;      // (one block per CU: nothing to balance)
-    c.by_len = (n >= 32u && n <= 1024u) ? reinterpret_cast<uint32_t*>(b + o_len) : nullptr;
-    c.rec_by_len = n >= 64u ? 1u : 0u;
+    c.order = (n > c.n_cu && n <= seg_max_jobs()) ? reinterpret_cast<uint32_t*>(b + o_ord) : nullptr;      // (one block per CU: nothing to balance)
+    c.by_len = (n >= (c.n_cu + 7u) / 8u && n <= seg_max_jobs()) ? reinterpret_cast<uint32_t*>(b + o_len) : nullptr;       // (MI355X: 32 jobs and more)
+    c.rec_by_len = n >= (c.n_cu + 3u) / 4u ? 1u : 0u;                                                                      // (64 and more)
     return true;
 }
 inline uint32_t seg_grid(uint32_t target, uint32_t n, uint32_t cap) {
@@ -161,7 +184,7 @@ int seg_launch(const lzf::seg_ctx& c, uint32_t upto, hipStream_t st) {
     const uint32_t n = c.n_jobs;
     // workgroups per launch of the chunk / tile kernels: about one chunk and a handful of tiles each — with 8 192 / 32 768 (each
     // workgroup looping over a dozen chunks) the launches ended on their slowest loops: parse 4.3 -> 3.3 ms at 980 blocks, 1.02 -> 0.83 at 196
-    uint32_t tg_parse = 262144u, tg_tile = 524288u;
+    uint32_t tg_parse = 1024u * c.n_cu, tg_tile = 2048u * c.n_cu;             // (MI355X: 262 144 and 524 288)
 #ifdef LZF_ANALYSIS      // LZF_SEG_GRID="parse,tiles": workgroups per launch of the chunk / tile kernels (A/B of the grid sizes)
     { static const char* e = getenv("LZF_SEG_GRID"); if (e) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a && b) { tg_parse = a; tg_tile = b; } } }
 #endif
@@ -181,12 +204,12 @@ int seg_launch(const lzf::seg_ctx& c, uint32_t upto, hipStream_t st) {
     return LZF_OK;
 }
 // The whole call: pipeline, then the pair kernel over what the pipeline did not finish.
-int seg_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n, uint32_t min_in, hipStream_t st, bool* used, uint64_t max_in_hint) {
+int seg_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n, uint32_t min_in, hipStream_t st, bool* used, uint64_t max_in_hint, uint32_t* ring_used) {
     SegScratch s;
-    *used = false;
+    *used = false; *ring_used = 0u;
     if (max_in_hint < min_in) return LZF_OK;                                      // (no job can be in the pipeline's window)
     if (!seg_alloc(s, d_jobs, d_results, n, min_in, st, max_in_hint)) return LZF_OK;      // (no scratch: the caller launches the pair kernel over everything)
-    *used = true;
+    *used = true; *ring_used = s.ctx.ring_bytes;
     int rc = seg_launch(s.ctx, 8u, st);
     if (rc == LZF_OK) {
         hipLaunchKernelGGL(k_paired48, dim3(n), dim3(128), 0, st, d_jobs, d_results, n, (const uint32_t*)nullptr, (const lzf::seg_job*)s.ctx.st);
@@ -238,7 +261,7 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
     AsyncScratch scratch_owner; scratch_owner.st = st;
     void*& scratch = scratch_owner.p;
     // the cost of a compress job is not known from its size: probe (aux_kernels.hip), then longest first
-    const bool want_order = use_order && use_compact && (table_kinds & LZF_KINDS_U32) && (use_order == 2u || n_jobs > 18u * cu_count());
+    const bool want_order = use_order && use_compact && (table_kinds & LZF_KINDS_U32) && (use_order == 2u || n_jobs > per_cu(8704u) * cu_count());      // (more jobs than compact-kernel waves the chip holds: 18 per CU)
     const uint32_t piece = 65536u, parts = 1u;      // one 64 KiB piece from the middle of each payload (more or smaller pieces order no better)
     const size_t n_probes = want_order ? (size_t)n_jobs * parts : 0u;
     const size_t probes_off = 256;                  // [queue of the rows variant][probe jobs][probe results][perm]
@@ -305,10 +328,11 @@ int lzf_decompress_batch_sized(const lzf_decompress_job* d_jobs, lzf_job_result*
 #endif
     // more blocks than the chip holds at once: longest (most compressed bytes) first
     AsyncScratch perm_owner; perm_owner.st = st;
-    uint32_t*& perm = reinterpret_cast<uint32_t*&>(perm_owner.p);
-    if (perm_ok && (use_order == 2u || (use_order == 1u && n_jobs > 8u * cu_count()))) {
+    uint32_t* perm = nullptr;
+    if (perm_ok && (use_order == 2u || (use_order == 1u && n_jobs > per_cu(20u * 1024u) * cu_count()))) {
         // perm[n] + est[n]: the jobs by their estimated cost, largest first
         if (hipMallocAsync(&perm_owner.p, 2u * sizeof(uint32_t) * (size_t)n_jobs, st) != hipSuccess) { (void)hipGetLastError(); perm_owner.p = nullptr; }   // (then: the caller's order)
+        perm = static_cast<uint32_t*>(perm_owner.p);
         if (perm) {
             uint32_t* const est = perm + n_jobs;
             uint32_t len_shift = 2u;       // a job's cost: its sequences + a quarter of its compressed bytes (measured: 403 GiB/s with the sequences alone, 414-418 with len >> 4 .. len >> 1)
@@ -330,7 +354,7 @@ int lzf_decompress_batch_sized(const lzf_decompress_job* d_jobs, lzf_job_result*
 #endif
     // Batches that leave the chip mostly empty with one workgroup per block: the segmented pipeline (a block decoded by many
     // wavefronts), then the pair kernel over the jobs it left (prefix / existing output, errors, sizes outside its window).
-    uint32_t seg_min_in = kSegMinIn; bool seg_on = n_jobs <= kSegMaxJobs;
+    uint32_t seg_min_in = kSegMinIn; bool seg_on = n_jobs <= seg_max_jobs();
 #ifdef LZF_ANALYSIS
     { static const int mode = [] { const char* e = getenv("LZF_DECOMPRESS_KERNEL"); return !e ? 0 : !strcmp(e, "seg") ? 1 : !strcmp(e, "noseg") ? 2 : 0; }();
       static const uint32_t min_in = [] { const char* e = getenv("LZF_SEG_MIN_IN"); return e ? (uint32_t)atol(e) : 0u; }();
@@ -338,18 +362,18 @@ int lzf_decompress_batch_sized(const lzf_decompress_job* d_jobs, lzf_job_result*
       if (mode == 2) seg_on = false; }
 #endif
     if (seg_on) {
-        bool used = false;
-        rc = seg_decompress(d_jobs, d_results, n_jobs, seg_min_in, st, &used, max_input_len);
-        if (used) g_last_decompress = n_jobs <= cu_count() ? "segmented: lzf_seg_resolve_pair_kernel<131072> + lzf_decompress_paired_kernel<4096,48,640>"
-                                     : n_jobs <= 2u * cu_count() ? "segmented: lzf_seg_resolve_pair_kernel<65536> + lzf_decompress_paired_kernel<4096,48,640>"
-                                                                 : "segmented: lzf_seg_resolve_pair_kernel<32768> + lzf_decompress_paired_kernel<4096,48,640>";
+        bool used = false; uint32_t ring = 0;
+        rc = seg_decompress(d_jobs, d_results, n_jobs, seg_min_in, st, &used, max_input_len, &ring);
+        if (used) g_last_decompress = ring == 131072u ? "segmented: lzf_seg_resolve_pair_kernel<131072> + lzf_decompress_paired_kernel<4096,48,640>"      // (the ring the call really used)
+                                     : ring == 65536u ? "segmented: lzf_seg_resolve_pair_kernel<65536> + lzf_decompress_paired_kernel<4096,48,640>"
+                                                      : "segmented: lzf_seg_resolve_pair_kernel<32768> + lzf_decompress_paired_kernel<4096,48,640>";
         if (rc != LZF_OK || used) { HIP_TRY(perm_owner.release()); return rc; }
     }
     // The producer/consumer pair kernel, with 48-byte regions while every block's workgroup is resident at once (lowest
     // latency per block: the copy stage is the critical path, the parse rides along) and 24-byte regions beyond that
     // (smaller LDS footprint, more blocks in flight); batches of more than eight times that many blocks (small blocks,
     // typically) go to the one-wave staged16 kernel, which has no per-block pipeline to fill.
-    const uint32_t resident48 = 8u * cu_count();          // workgroups of the 48-byte form one device holds: 8 per CU (20 KB of LDS each)
+    const uint32_t resident48 = per_cu(20u * 1024u) * cu_count();      // workgroups of the 48-byte form one device holds (20 KB of LDS each: 8 per CU on MI355X)
     g_last_decompress = n_jobs <= resident48 ? "lzf_decompress_paired_kernel<4096,48,640>" : n_jobs <= 8u * resident48 ? "lzf_decompress_paired_kernel<4096,24,384>"
                                                                                                              : "lzf_decompress_batched_kernel<4096,16,256,staged>";
     if (n_jobs <= resident48)

@@ -49,7 +49,7 @@ __global__ __launch_bounds__(128) void lzf_decompress_paired_kernel(
     long long ph_acc_out = 0;
 #endif
 #ifdef LZF_DBG_ROUNDS
-    uint32_t dbg_rounds = 0, dbg_batches = 0;
+    uint32_t dbg_rounds = 0, dbg_batches = 0, dbg_lane_stat = 0;
 #endif
     if (job.input_len >= kMaxPosB || job.out_existing_len >= kMaxPosB || job.prefix_len >= kMaxPosB || job.out_existing_len > job.out_cap) {
         status = LZF_CONTRACT;                         // (uniform over the workgroup: no barrier is reached)
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(128) void lzf_decompress_paired_kernel(
 #ifdef LZF_DBG_PHASE_SEL
         results[jid].reserved = (uint32_t)(ph_acc_out >> 10);
 #elif defined(LZF_DBG_ROUNDS)
-        results[jid].reserved = LZF_DBG_ROUNDS == 1 ? dbg_rounds : dbg_batches;
+        results[jid].reserved = LZF_DBG_ROUNDS == 1 ? dbg_rounds : LZF_DBG_ROUNDS == 2 ? dbg_batches : dbg_lane_stat;
 #else
         results[jid].reserved = (uint32_t)((clock64() - t_start) >> 10);   // diagnostic: shader kilo-cycles spent on this job
 #endif

@@ -34,8 +34,14 @@ def compress_batch(d_jobs, d_res, n, kinds=ffi.KINDS_U32, stream=None):
     ffi.check(ffi.lib().lzf_compress_batch(d_jobs.data_ptr(), d_res.data_ptr(), n, kinds, _stream_ptr(stream)))
 
 
-def decompress_batch(d_jobs, d_res, n, stream=None):
-    ffi.check(ffi.lib().lzf_decompress_batch(d_jobs.data_ptr(), d_res.data_ptr(), n, _stream_ptr(stream)))
+def decompress_batch(d_jobs, d_res, n, stream=None, max_input_len=None):
+    """lzf_decompress_batch; with max_input_len (an upper bound of the jobs' input_len, which the caller of a device-resident
+    job array usually knows) lzf_decompress_batch_sized: the segmented pipeline then sizes its scratch for that bound instead
+    of for 4 MiB blocks at their worst case — a batch of small blocks allocates (and launches) next to nothing."""
+    if max_input_len is None:
+        ffi.check(ffi.lib().lzf_decompress_batch(d_jobs.data_ptr(), d_res.data_ptr(), n, _stream_ptr(stream)))
+    else:
+        ffi.check(ffi.lib().lzf_decompress_batch_sized(d_jobs.data_ptr(), d_res.data_ptr(), n, int(max_input_len), _stream_ptr(stream)))
 
 
 def xxh32_batch(d_ptrs, d_lens, d_out, n, stream=None):

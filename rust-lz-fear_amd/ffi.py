@@ -118,6 +118,7 @@ def lib():
         L.lzf_last_decompress_launch.restype = C.c_char_p
         L.lzf_compress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.lzf_decompress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+        L.lzf_decompress_batch_sized.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
         L.lzf_table_seed_from_dictionary.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
         L.lzf_table_offset.argtypes = [C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]
         L.lzf_xxh32_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]

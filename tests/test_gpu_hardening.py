@@ -106,3 +106,12 @@ def test_segmented_pipeline_fallbacks_forced(force):
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "force ok" in r.stdout
+
+
+def test_dispatch_thresholds_follow_the_device_geometry():
+    """Review r3 item 7: no literal 1 024 / 262 144 / 8 x 256 in the dispatch — with LZF_FAKE_CU=64 (analysis library) every
+    threshold moves to the 64-CU value, every class of batch size is crossed, and every block decodes to the oracle's bytes."""
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "fake_cu_check.py")], env=_analysis_env(LZF_FAKE_CU="64"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "geometry ok" in r.stdout
