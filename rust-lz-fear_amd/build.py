@@ -21,11 +21,11 @@ ANALYSIS_LIB_PATH = os.path.join(PKG_DIR, "liblzfear_hip_analysis.so")
 
 PRODUCT_HIP = ["capi.hip", "lz4_decompress_batched.hip", "lz4_decompress_paired.hip", "lz4_decompress_seg.hip", "lz4_compress.hip",
                "lz4_compress_compact.hip", "aux_kernels.hip"]
-ANALYSIS_HIP = ["lz4_decompress.hip", "lz4_decompress_windowed.hip", "lz4_decompress_v6.hip", "lz4_compress_rows.hip"]
+ANALYSIS_HIP = ["analysis/lz4_decompress.hip", "analysis/lz4_decompress_windowed.hip", "analysis/lz4_decompress_v6.hip", "analysis/lz4_compress_rows.hip"]
 CXX_SOURCES = ["frame.cpp", "host_staging.cpp"]
 HEADERS = ["kernels.h", "lzf_device.h", "lz4_decompress_batch_phase.inc", "lz4_decompress_parse_phase.inc",
-           "lz4_decompress_copy3.inc",
-           "lz4_decompress_gwalk_phase.inc", "lzf_copy_helpers.h", "lzf_parse_helpers.h", "lzf_compress_common.h", "lzf_simt.h", "lz4_compress_rows.inc",
+           "analysis/lz4_decompress_copy3.inc", "analysis/capi_analysis.inc",
+           "analysis/lz4_decompress_gwalk_phase.inc", "lzf_copy_helpers.h", "lzf_parse_helpers.h", "lzf_compress_common.h", "lzf_simt.h", "analysis/lz4_compress_rows.inc",
            "host_staging.h",
            os.path.join(ROOT, "include", "lzfear_hip.h"), os.path.join(ROOT, "include", "lzfear_frame.h")]
 
@@ -70,7 +70,7 @@ def build_library(force=False, verbose=False, defines=(), out=None, analysis=Fal
     jobs = []
     for s in _sources(analysis):
         src = _path(s)
-        obj = os.path.join(objdir, os.path.splitext(s)[0] + ".o")
+        obj = os.path.join(objdir, os.path.splitext(os.path.basename(s))[0] + ".o")
         stale = force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t)
         jobs.append((src, obj, stale))
     todo = [(s, o) for s, o, st in jobs if st]

@@ -3,7 +3,7 @@
 // lock-step emulator); this file instantiates it with the gfx950 primitives.  One wave per workgroup, 34 KiB of LDS: four
 // workgroups per CU, one per SIMD.
 #include "lz4_compress_rows.inc"
-#include "kernels.h"
+#include "../kernels.h"
 
 namespace lzf {
 

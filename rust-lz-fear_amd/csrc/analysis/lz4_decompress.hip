@@ -16,7 +16,7 @@
 //
 // Error precedence is the reference's (decompress.rs:63-75,82-89): literal EOF, LSIC EOF ->
 // UnexpectedEnd; then MemoryLimitExceeded; ZeroDeduplicationOffset; InvalidDeduplicationOffset.
-#include "lzf_device.h"
+#include "../lzf_device.h"
 
 namespace lzf {
 

@@ -12,10 +12,10 @@
 // Splitting the pair of (retired) v5 pair kernel in two launches doubles the copy waves a CU holds (they are the critical path)
 // and lets each kernel have its own register budget; the price is the token lists in HBM (4 bytes per sequence written and
 // read once: + ~30 % traffic on top of the compressed and decoded bytes).
-#include "lzf_device.h"
-#include "kernels.h"
-#include "lzf_copy_helpers.h"
-#include "lzf_parse_helpers.h"
+#include "../lzf_device.h"
+#include "../kernels.h"
+#include "../lzf_copy_helpers.h"
+#include "../lzf_parse_helpers.h"
 #include <type_traits>
 
 namespace lzf {

@@ -21,9 +21,9 @@
 // decompress.rs:61-71 (token, LSIC lengths, literals, offset) is what a hop steps over; tokens the plain
 // view cannot express (0xFF length bytes, literal runs longer than the window, the last 24 bytes of the
 // input) are taken one at a time by the general routine.
-#include "lzf_device.h"
-#include "kernels.h"
-#include "lzf_copy_helpers.h"
+#include "../lzf_device.h"
+#include "../kernels.h"
+#include "../lzf_copy_helpers.h"
 
 namespace lzf {
 
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_windowed_kernel(
             wave_store_fence();                                          // the token list is read back below
 
 #define LZF_TOKEN_AT(i) ((uint32_t)gtoks[(i)])
-#include "lz4_decompress_batch_phase.inc"
+#include "../lz4_decompress_batch_phase.inc"
 #undef LZF_TOKEN_AT
             if (status == LZF_OK && cerr != LZF_OK) status = cerr;
             cstart = cend;

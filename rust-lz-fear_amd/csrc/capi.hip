@@ -1,7 +1,7 @@
 // capi.hip — the extern "C" boundary declared in include/lzfear_hip.h.
 // Plain HIP runtime calls + kernel launches; no CPU codec anywhere in this file: without a
 // usable HIP device every entry point fails with LZF_E_NO_DEVICE.  The product library reads no
-// environment variables; the A/B knobs of the analysis build live in capi_analysis.inc.
+// environment variables; the A/B knobs of the analysis build live in analysis/capi_analysis.inc.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -221,7 +221,7 @@ int seg_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, 
 }
 
 #ifdef LZF_ANALYSIS
-#include "capi_analysis.inc"
+#include "analysis/capi_analysis.inc"
 #endif
 
 }  // namespace
@@ -251,7 +251,7 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
     uint32_t use_compact = 1u, use_order = 1u, use_rows = 0u;
 #ifdef LZF_ANALYSIS
     // LZF_COMPRESS_KERNEL = general (everything on lzf_compress_wave_kernel) | rows (round 4's four-blocks-per-wavefront kernel,
-    // lz4_compress_rows.hip: measured slower than the compact kernel at every batch size, kept as a variant; profiles/r04_compress_rows.txt)
+    // analysis/lz4_compress_rows.hip: measured slower than the compact kernel at every batch size, kept as a variant; profiles/r04_compress_rows.txt)
     { static const uint32_t which = [] { const char* e = getenv("LZF_COMPRESS_KERNEL"); return !e ? 0u : !strcmp(e, "general") ? 1u : !strcmp(e, "rows") ? 2u : 0u; }();
       static const uint32_t order = analysis_order("LZF_COMPRESS_ORDER");
       use_compact = which == 1u ? 0u : 1u; use_rows = which == 2u ? 1u : 0u; use_order = order; }

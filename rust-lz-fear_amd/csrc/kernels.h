@@ -165,7 +165,7 @@ __global__ void lzf_compress_compact_kernel(const lzf_compress_job* __restrict__
 extern template __global__ void lzf_compress_compact_kernel<false>(const lzf_compress_job*, lzf_job_result*, uint32_t, const uint32_t*, uint32_t);
 extern template __global__ void lzf_compress_compact_kernel<true>(const lzf_compress_job*, lzf_job_result*, uint32_t, const uint32_t*, uint32_t);
 #ifdef LZF_ANALYSIS
-// four blocks per wavefront, persistent waves (lz4_compress_rows.hip / .inc; round 4, analysis variant): the compact-table jobs of a
+// four blocks per wavefront, persistent waves (analysis/lz4_compress_rows.hip / .inc; round 4, analysis variant): the compact-table jobs of a
 // batch; queue = next position of perm[] (or of the job array) to hand out, zero before the launch; rows_active = rows of a wave that take jobs
 __global__ void lzf_compress_rows_kernel(const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
                                          const uint32_t* __restrict__ perm, uint32_t* __restrict__ queue, uint32_t rows_active, uint32_t alone);

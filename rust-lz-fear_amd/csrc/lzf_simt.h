@@ -1,4 +1,4 @@
-// lzf_simt.h — the handful of wave-level primitives the row-mapped compress kernel (lz4_compress_rows.inc) is written in.
+// lzf_simt.h — the handful of wave-level primitives the row-mapped compress kernel (analysis/lz4_compress_rows.inc) is written in.
 //
 // The kernel body is per-lane code with WAVE-UNIFORM control flow around every cross-lane operation: all 64 lanes call
 // every primitive below, in the same order, with a per-lane predicate.  Two backends:

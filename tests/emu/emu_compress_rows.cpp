@@ -1,5 +1,5 @@
 // emu_compress_rows.cpp — TEST INFRASTRUCTURE ONLY: runs the source of the row-mapped compress kernel
-// (rust-lz-fear_amd/csrc/lz4_compress_rows.inc) on the CPU under the lock-step wavefront emulator of lzf_simt.h, so that the
+// (rust-lz-fear_amd/csrc/analysis/lz4_compress_rows.inc) on the CPU under the lock-step wavefront emulator of lzf_simt.h, so that the
 // CPU suite (tests/test_emu_compress_rows.py) can compare the kernel's logic with the oracle without a GPU.  One fiber per lane,
 // resumed round-robin at every cross-lane primitive; the waves of a launch run one after the other (they only share the job
 // queue).  Nothing of this is in the product library; the product path fails without a HIP device.
@@ -7,7 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
-#include "../../rust-lz-fear_amd/csrc/lz4_compress_rows.inc"
+#include "../../rust-lz-fear_amd/csrc/analysis/lz4_compress_rows.inc"
 
 #if !defined(__x86_64__)
 #error "the fiber switch below is x86-64 System V"

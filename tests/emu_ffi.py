@@ -1,6 +1,6 @@
 """ctypes binding of tests/emu/libemu_compress_rows.so — TEST INFRASTRUCTURE ONLY.
 
-The library is the source of the row-mapped compress kernel (rust-lz-fear_amd/csrc/lz4_compress_rows.inc) compiled with g++
+The library is the source of the row-mapped compress kernel (rust-lz-fear_amd/csrc/analysis/lz4_compress_rows.inc) compiled with g++
 against the lock-step wavefront emulator of lzf_simt.h; see tests/emu/emu_compress_rows.cpp.  The product never loads it.
 """
 import ctypes as C
@@ -28,7 +28,7 @@ _lib = None
 def build(force=False):
     so = os.path.join(EMU_DIR, "libemu_compress_rows.so")
     deps = [os.path.join(EMU_DIR, "emu_compress_rows.cpp")] + [os.path.join(CSRC, f) for f in
-            ("lz4_compress_rows.inc", "lzf_simt.h", "lzf_compress_common.h")] + [os.path.join(INCLUDE, "lzfear_hip.h")]
+            ("analysis/lz4_compress_rows.inc", "lzf_simt.h", "lzf_compress_common.h")] + [os.path.join(INCLUDE, "lzfear_hip.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-o", so, deps[0]])
     return so

@@ -1,4 +1,4 @@
-"""The row-mapped compress kernel's SOURCE (rust-lz-fear_amd/csrc/lz4_compress_rows.inc), compiled for the CPU against the lock-step
+"""The row-mapped compress kernel's SOURCE (rust-lz-fear_amd/csrc/analysis/lz4_compress_rows.inc), compiled for the CPU against the lock-step
 wavefront emulator of lzf_simt.h, must produce the oracle's bytes — raw::compress2 (src/raw/compress/mod.rs:165-238) with a fresh
 U32Table or a read-only template.  No GPU: this is the kernel's parse / commit / emit logic (batches of 16 probes per row, four rows
 per wave, collision cuts, epoch sweeps of the compact table, the skip schedule, match extension, backtrack, cap = N refusals, the
