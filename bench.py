@@ -151,17 +151,20 @@ def cpu_baseline(raw_blocks, comp_blocks, budget_s):
 
 # --------------------------------------------------------------------------------------- HBM traffic (PMC passes under profiles/)
 def traffic_for(kernel_name, which, n_jobs):
-    """FETCH_SIZE (x2: gfx950 correction) + WRITE_SIZE of the launched kernel, from the separate --pmc passes committed as
-    profiles/r02_hbm_traffic.json (tools/refresh_profiles.sh), scaled by job count; None when the profile is of another kernel."""
-    path = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")
-    if not os.path.exists(path):
-        path = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
-    if not os.path.exists(path):
-        return None
-    tj = json.load(open(path)).get(which)
+    """HBM bytes per launch of the named kernel: FETCH_SIZE (x2: gfx950 correction) + WRITE_SIZE from the separate --pmc passes
+    committed under profiles/ (tools/refresh_profiles.sh), SCALED by job count from the pass's own (smaller) batch — the second
+    value says from how many copies; (None, None) when the committed profile is of another kernel."""
+    tj = path = None
+    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(path):
+            tj = json.load(open(path)).get(which)
+            break
     if not tj or tj.get("kernel") != kernel_name:
-        return None
-    return (2 * tj["FETCH_SIZE_KB"] + tj["WRITE_SIZE_KB"]) * 1024.0 * n_jobs / tj["jobs"]
+        return None, None
+    return ((2 * tj["FETCH_SIZE_KB"] + tj["WRITE_SIZE_KB"]) * 1024.0 * n_jobs / tj["jobs"],
+            {"kind": "scaled from a separate PMC pass", "scaled_from_copies": int(round(tj["jobs"] / (49.0 if which == "decompress" else 51.0))),
+             "scaled_from_jobs": int(tj["jobs"]), "profile": os.path.basename(path)})
 
 
 def last_decompress_launch(ffi):
@@ -173,7 +176,7 @@ def issue_ceiling(copies, kernel_ms, achieved_gbs, cus=256):
     ipseq, seq_per_copy, best_rate = 27.96, 11.71e6, 3.29            # wave-instructions per sequence; sequences per copy; instr / ns / CU (32 waves per CU)
     rate = ipseq * seq_per_copy * copies / (kernel_ms * 1e-3) / 1e9 / cus
     ceil_gbs = achieved_gbs * best_rate / rate
-    return {"wave_instructions_per_sequence": ipseq, "retired_per_ns_per_cu": round(rate, 3), "best_measured_mix_per_ns_per_cu": best_rate,
+    return {"kind": "model (constants from the r01 / r02 counter passes, not re-measured in this run; only kernel_ms is this run's)", "wave_instructions_per_sequence": ipseq, "retired_per_ns_per_cu": round(rate, 3), "best_measured_mix_per_ns_per_cu": best_rate,
             "ceiling_gbs": round(ceil_gbs, 1), "ceiling_frac_of_hbm": round(ceil_gbs / HBM_PEAK_GBS, 4), "achieved_frac_of_ceiling": round(rate / best_rate, 3)}
 
 
@@ -429,8 +432,8 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
 
     d_bytes = float(lens[kidx].sum() + clen[kidx].sum())               # C + N of the kernel's jobs
     kname = kname_main
-    d_traffic = traffic_for(kname, "decompress", nk)
-    c_traffic = traffic_for("lzf_compress_compact_kernel<false>", "compress", nblk)
+    d_traffic, d_traffic_info = traffic_for(kname, "decompress", nk)
+    c_traffic, c_traffic_info = traffic_for("lzf_compress_compact_kernel<false>", "compress", nblk)
     d_achieved = d_bytes / (d_kernel_ms * 1e-3) / 1e9
     c_achieved = c_bytes / (c_kernel_ms * 1e-3) / 1e9
 
@@ -485,13 +488,14 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
                                "rotated + XOR-ed), 4 MiB independent blocks, decompress_raw of every block (configs[1]); lz4 ratio %.3f" %
                                (copies, len(bases), float(lens.sum()) / float(clen.sum() + lens[stored_idx].sum())),
                    "blocks_per_gpu": int(nblk), "stored_blocks_per_gpu": int(len(stored_idx)),
-                   "block_size": BS, "parallelism": f"block-sharded x{world}, no collective"},
+                   "block_size": BS, "parallelism": f"block-sharded x{world}, no collective",
+                   "cu_count": int(torch.cuda.get_device_properties(dev).multi_processor_count)},     # what the library's dispatch thresholds are derived from
         # the kernel alone over the compressed blocks (the stored ones are a device memcpy beside it)
         "kernel_only": {"value": round(kernel_bytes / world / (d_kernel_ms * 1e-3) / 2**30 * world, 3), "unit": "GiB/s over the compressed blocks only",
                         "blocks_per_gpu": int(nk)},
         "roofline": {"bound": "hbm", "kernel": kname,
                      "achieved": round(d_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(d_achieved / HBM_PEAK_GBS, 5), "traffic": d_traffic,
+                     "frac": round(d_achieved / HBM_PEAK_GBS, 5), "traffic": d_traffic, "traffic_provenance": d_traffic_info,
                      "algorithmic_bytes_per_launch": d_bytes, "kernel_ms": round(d_kernel_ms, 4),
                      "north_star_frac": round(float(lens[kidx].sum()) / (d_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                      # what one workgroup per block can reach at its instruction count: SQ counters of the launched kernel
@@ -502,7 +506,7 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
                      "steps": c_steps, "ms_per_step": round(tc_max / c_steps * 1e3, 3),
                      "roofline": {"bound": "hbm", "kernel": "lzf_compress_compact_kernel<false>",
                                   "achieved": round(c_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                  "frac": round(c_achieved / HBM_PEAK_GBS, 5), "traffic": c_traffic,
+                                  "frac": round(c_achieved / HBM_PEAK_GBS, 5), "traffic": c_traffic, "traffic_provenance": c_traffic_info,
                                   "algorithmic_bytes_per_launch": c_bytes, "kernel_ms": round(c_kernel_ms, 3)}},
         # the same call at smaller batch sizes (compressed blocks of the first 1 / 4 / 20 copies; kernel time by HIP events,
         # median of 5): up to 1024 blocks go through the segmented pipeline, a block decoded by many wavefronts
@@ -685,7 +689,7 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
                    "frame_bytes": int(state["frame_len"]), "wire_bytes_in_per_rank": int(wire), "verified_against_oracle_prefix": verified,
                    "gather_ms": round(g_ms, 3), "n_ranks_seen_by_rccl": (dist.get_world_size() if dist else 0), "content_checksum": xx},
         "roofline": {"bound": "hbm", "kernel": "lzf_compress_compact_kernel<false>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_for("lzf_compress_compact_kernel<false>", "compress", nloc),
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_for("lzf_compress_compact_kernel<false>", "compress", nloc)[0],
                      "algorithmic_bytes_per_launch": alg, "kernel_ms": round(k_ms, 4)},
         "cpu_baseline": cpu,
     }

@@ -58,17 +58,26 @@ pub mod raw {
     /// the `_many` / batch entry points (lzf_frame_compress_many, lzf_frame_writer_*), never this wrapper in a loop.
     pub fn compress2<W: Write, T: GpuTable>(input: &[u8], cursor: usize, table: &mut T, mut writer: W) -> io::Result<()> {
         assert!(input.len() <= T::payload_size_limit()); // mod.rs:167
-        struct Sink<'a> { w: &'a mut dyn Write, err: Option<io::Error> }
+        struct Sink<'a> { w: &'a mut dyn Write, err: Option<io::Error>, panic: Option<Box<dyn std::any::Any + Send>> }
+        // A panic of the user's writer must not unwind through the C frames of lzf_compress2_host_writer (undefined
+        // behaviour): it is caught here, the writer "refuses" (non-zero), and the panic resumes once the FFI call has
+        // returned — the caller sees what the reference's compress2 would show it: the writer's own panic.
         unsafe extern "C" fn write_all(ctx: *mut std::ffi::c_void, data: *const u8, len: usize) -> i32 {
             let s = &mut *(ctx as *mut Sink);
-            match s.w.write_all(std::slice::from_raw_parts(data, len)) { Ok(()) => 0, Err(e) => { s.err = Some(e); 1 } }
+            let bytes = std::slice::from_raw_parts(data, len);
+            match std::panic::catch_unwind(std::panic::AssertUnwindSafe(|| s.w.write_all(bytes))) {
+                Ok(Ok(())) => 0,
+                Ok(Err(e)) => { s.err = Some(e); 1 }
+                Err(p) => { s.panic = Some(p); 2 }
+            }
         }
-        let mut sink = Sink { w: &mut writer, err: None };
+        let mut sink = Sink { w: &mut writer, err: None, panic: None };
         let mut werr = 0i32;
         let rc = unsafe {
             sys::lzf_compress2_host_writer(input.as_ptr(), input.len() as u64, cursor as u64, table.as_mut_ptr(), T::KIND,
                                            Some(write_all), &mut sink as *mut _ as *mut _, &mut werr)
         };
+        if let Some(p) = sink.panic.take() { std::panic::resume_unwind(p) }
         match rc {
             sys::LZF_OK => Ok(()),
             sys::LZF_OUTPUT_FULL => Err(sink.err.take().unwrap_or_else(|| ErrorKind::ConnectionAborted.into())), // e.g. NoPartialWrites, framed/compress.rs:300

@@ -34,10 +34,10 @@ class LZ4FrameWriter:
 
         def cb(ctx, p, n):
             try:
-                sink(bytes(p[:n]))
+                sink(C.string_at(p, n))         # (one memcpy; a slice of the POINTER would build a list of n Python ints first)
                 return 0
-            except Exception as e:              # the sink refuses: the writer stops (io::Error of the reference's writer)
-                self._exc = e
+            except BaseException as e:          # the sink refuses: the writer stops (io::Error of the reference's writer);
+                self._exc = e                   # KeyboardInterrupt and friends are re-raised by _done as well
                 return 1
         self._cb = self._WRITE(cb)
         self._s = settings._struct(content_size)
@@ -53,8 +53,9 @@ class LZ4FrameWriter:
             raise FrameError(rc)
 
     def _done(self, rc):
-        if rc == ffi.OUTPUT_FULL and self._exc is not None:
-            raise self._exc
+        if self._exc is not None:               # whatever the sink raised comes back to the caller, whatever status the C side made of it
+            e, self._exc = self._exc, None
+            raise e
         if rc != 0:
             ffi.check(rc)
             raise FrameError(rc)
