@@ -1,14 +1,14 @@
 #!/bin/bash
 # Regenerates the round's measurement artifacts on the GPU box (run through gpurun from the repo root), product library only:
-#   gpurun_out/r03/bench_default.json          python bench.py (the driver's default invocation)
-#   gpurun_out/r03/kernel_stats.txt            rocprofv3 --kernel-trace --stats of the same command
-#   gpurun_out/r03/pmc_{FETCH,WRITE}_SIZE.txt  separate --pmc passes at 48 copies (1 step; 2352 compressed blocks: the same kernels
+#   gpurun_out/r04/bench_default.json          python bench.py (the driver's default invocation)
+#   gpurun_out/r04/kernel_stats.txt            rocprofv3 --kernel-trace --stats of the same command
+#   gpurun_out/r04/pmc_{FETCH,WRITE}_SIZE.txt  separate --pmc passes at 48 copies (1 step; 2352 compressed blocks: the same kernels
 #                                               as the default run — counter collection at 240 copies does not finish) for HBM traffic
-#   gpurun_out/r03/hbm_traffic.json            the two passes as the file bench.py reads (copy to profiles/r03_hbm_traffic.json)
-#   gpurun_out/r03/bench_config4.json          python bench.py --workload config4
-#   gpurun_out/r03/bench_240x48.json, bench_240x1.json   seed-sensitivity check at full size: 240 copies from 48 seeds / from 1 seed
+#   gpurun_out/r04/hbm_traffic.json            the two passes as the file bench.py reads (copy to profiles/r04_hbm_traffic.json)
+#   gpurun_out/r04/bench_config4.json          python bench.py --workload config4
+#   gpurun_out/r04/bench_240x48.json, bench_240x1.json   seed-sensitivity check at full size: 240 copies from 48 seeds / from 1 seed
 set -u
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03; rm -rf $O; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04; rm -rf $O; mkdir -p $O
 cd $R && timeout 1500 python bench.py > $O/bench_default.log 2>&1; tail -1 $O/bench_default.log > $O/bench_default.json
 cd /tmp; export TMPDIR=/tmp
 (cd $R && timeout 1500 rocprofv3 --kernel-trace --stats -d $O/prof -o x -- python bench.py --no-cpu --no-e2e --no-config4 > $O/prof.log 2>&1)
@@ -39,7 +39,7 @@ def per_dispatch(counter, needle):
             best = (p[1], float(p[5].split()[-1]), p[3].split()[-1])
     return best
 out = {"_what": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace) of `python bench.py --copies 48 --distinct 1 --steps 1 --warmup 0 --no-cpu --no-e2e --no-verify` "
-                "(48 copies: the same kernels as the default 240-copy run; bench.py scales by job count) on MI355X, round 3; per dispatch, in the counters' KB units (x1024 bytes). "
+                "(48 copies: the same kernels as the default 240-copy run; bench.py scales by job count) on MI355X, round 4; per dispatch, in the counters' KB units (x1024 bytes). "
                 "gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half of the bytes of wide streaming reads; bench.py uses 2 x FETCH + WRITE as the upper bound."}
 dk = line["roofline"]["kernel"].replace(",", ", ")        # the launched variant exactly, as rocprofv3 prints it (the batch sweep launches others)
 for which, needle, jobs in (("decompress", dk, line["kernel_only"]["blocks_per_gpu"]), ("compress", "lzf_compress_compact_kernel<false>", line["config"]["blocks_per_gpu"])):
