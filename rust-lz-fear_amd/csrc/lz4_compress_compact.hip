@@ -271,8 +271,17 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     if ((wpk & 0x210u) == 0u && inrange >= 0) {
                         if (DRY) ++work;
                         cursor = cur2;                                                 // :215
-                        const uint32_t lt = lane > nl2 ? lane - nl2 : 0u, lj = lt < L2 ? lt : L2;
-                        uint32_t byte = in[ls + (lj ? lj - 1u : 0u)];                // lane j: literal j - 1 - nl2
+                        // lane j: literal j - 1 - nl2.  A run that ends in its first batch has them in registers — lane k probed
+                        // position ls + k, the low byte of its A0 is literal k — one or two lanes to the left (round 4: the byte load this
+                        // replaces was one more access for the next probe bytes' wait to include; vmcnt counts in order)
+                        uint32_t byte;
+                        if (n == 0u) {
+                            const uint32_t b1 = wave_prev((uint32_t)A0 & 0xFFu, 0u), b2 = wave_prev(b1, 0u);
+                            byte = nl2 ? b2 : b1;
+                        } else {
+                            const uint32_t lt = lane > nl2 ? lane - nl2 : 0u, lj = lt < L2 ? lt : L2;
+                            byte = in[ls + (lj ? lj - 1u : 0u)];
+                        }
                         pfA0 = 0; pfA1 = 0;                                            // the next run's probe bytes, right behind
                         if (lane < kProbeLanes) { pfA0 = ld8(in + cur2 + lane); pfA1 = ld8(in + cur2 + lane + 8u); }
                         pf_c = cur2;
