@@ -217,9 +217,22 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                         : "=&v"(gt), "=&v"(inr) : "v"(xk), "v"(s16), "v"(lane), "s"(dcut));
                     const uint32_t okv = ((gt & e1 & diff) | ((gt ^ 1u) & (diff ^ 1u))) & inr;   // <=> in the batch, cand <= ck && ck - cand <= 0xFFFF
                     const bool reach = okv != 0u;
+                    // The 8 bytes before a probe (backtrack, :211-212).  In a run's first batch the backtrack of lane k stops after k
+                    // bytes (:211: cursor - literal_start), so only input[ls .. ls + k) matters — and that is in the lanes' registers:
+                    // lane k >= 8 takes lane k - 8's probe bytes, lane k < 8 the run's first k bytes in the top of the word (the rest
+                    // is never looked at: the bound cuts it off).  One load fewer per sequence; worked out behind the gather's issue.
+                    const bool pa_regs = n == 0u;
                     if (reach) {
                         B0 = ld8(in + cand); B1 = ld8(in + cand + 8u);
-                        PA = ld8(in + ck - 8u); PB = ld8(in + ((cand - 8u) & (0u - lt01(7u, cand))));   // (unused when cand < 8)
+                        if (!pa_regs) PA = ld8(in + ck - 8u);
+                        PB = ld8(in + ((cand - 8u) & (0u - lt01(7u, cand))));   // (unused when cand < 8)
+                    }
+                    if (pa_regs) {
+                        const uint32_t lo = (uint32_t)A0, hi = (uint32_t)(A0 >> 32);
+                        const uint32_t slo = LZF_DPP(0, lo, 0x118 /* row_shr:8 */, 0xf), shi = LZF_DPP(0, hi, 0x118, 0xf);
+                        const uint64_t first8 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, 0) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)lo, 0);
+                        const uint32_t k7 = lane & 7u;
+                        PA = (lane & 8u) ? (((uint64_t)shi << 32) | slo) : (first8 << ((8u - k7) * 8u - (k7 ? 0u : 1u)));
                     }
                     const bool valid = reach && (uint32_t)A0 == (uint32_t)B0;  // :204-206 (m >= 4)
                     W = first_lane(__ballot(valid));
