@@ -75,6 +75,13 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
     long long g_tph[6] = {0, 0, 0, 0, 0, 0};
 #endif
     Sink s{as_global(job.out), 0u, job.out_cap > kMaxLen ? kMaxLen : (uint32_t)job.out_cap};
+    // The common sequence's one store is DEFERRED to the next batch, behind the issue of its gather: a wave's loads and stores are
+    // acknowledged in order, so a store issued at the end of a sequence is still on its way when the next probe bytes are waited for;
+    // issued behind the gather it is the newest access at the gather's wait (vmcnt(1)) and long gone at the next one.
+    uint32_t ps_n = 0, ps_pos = 0, ps_byte = 0;          // bytes pending (0: none), their place in the output, lane l's byte
+    auto flush_ps = [&]() {
+        if (ps_n) { if (!DRY && lane < ps_n) s.out[ps_pos + lane] = (uint8_t)ps_byte; ps_n = 0; }
+    };
     {
         const uint32_t len = (uint32_t)job.input_len;
         const uint32_t init = (uint32_t)job.cursor;                      // :169
@@ -227,6 +234,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                         if (!pa_regs) PA = ld8(in + ck - 8u);
                         PB = ld8(in + ((cand - 8u) & (0u - lt01(7u, cand))));   // (unused when cand < 8)
                     }
+                    flush_ps();                       // (the previous sequence's store: behind this batch's gather)
                     if (pa_regs) {
                         const uint32_t lo = (uint32_t)A0, hi = (uint32_t)(A0 >> 32);
                         const uint32_t slo = LZF_DPP(0, lo, 0x118 /* row_shr:8 */, 0xf), shi = LZF_DPP(0, hi, 0x118, 0xf);
@@ -304,7 +312,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                         if (lane == 0u) byte = ((nl2 ? 15u : L2) << 4) | ex2;
                         if (lane == L2 + nl2 + 1u) byte = off2;
                         if (lane == L2 + nl2 + 2u) byte = off2 >> 8;
-                        if (!DRY && lane < L2 + nl2 + 3u) s.out[s.pos + lane] = (uint8_t)byte;
+                        ps_byte = byte; ps_pos = s.pos; ps_n = L2 + nl2 + 3u;           // (stored behind the next batch's gather)
                         s.pos += L2 + nl2 + 3u;
                         PCOUNT(pc_straight);
                         straight = true;
@@ -354,6 +362,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                             if (lane == 0u) byte = (L3 << 4) | (ex3 < 15u ? ex3 : 15u);
                             if (lane == L3 + 1u) byte = off3;
                             if (lane == L3 + 2u) byte = off3 >> 8;
+                            flush_ps();
                             if (!DRY && lane < tot3) s.out[s.pos + lane] = (uint8_t)byte;
                             s.pos += tot3;
                             PCOUNT(pc_ext);
@@ -364,6 +373,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             }
             // ================= search: speculative batches of the :177-232 loop
             if (!found) for (;;) {
+                flush_ps();
                 if (DRY) ++work;
                 PCOUNT(pc_bgen);
                 { const uint32_t eb = c >> 16; if (eb != swept) sweep_to(eb); }        // the batch base enters a new 64 KiB epoch
@@ -496,6 +506,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             CPHASE(1);
 
             if (finished) {
+                flush_ps();
                 // ---- last literals, mod.rs:178-190
                 const uint32_t L = len - ls;
                 const uint32_t nl = lsic_len(L);
@@ -614,6 +625,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             // ================= write_group, mod.rs:150-163 (+ :235 literal slice)
             const uint32_t lit_end = cursor - extra - 4u;
             const uint32_t L = lit_end - ls;
+            flush_ps();
             if (L < 15u && extra < 15u) {
                 // the common sequence: token, up to 14 literals, offset — one byte per lane, one store
                 const uint32_t total = L + 3u;
@@ -657,6 +669,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             CPHASE(3);
         }
     }
+    flush_ps();
 #ifdef LZF_DBG_PATHS
     if (lane == 0 && job.out_cap >= 24u) {
         LZF_GLOBAL uint32_t* pc = (LZF_GLOBAL uint32_t*)as_global(job.out);
