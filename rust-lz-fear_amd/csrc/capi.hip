@@ -262,7 +262,10 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
     void*& scratch = scratch_owner.p;
     // the cost of a compress job is not known from its size: probe (aux_kernels.hip), then longest first
     const bool want_order = use_order && use_compact && (table_kinds & LZF_KINDS_U32) && (use_order == 2u || n_jobs > per_cu(8704u) * cu_count());      // (more jobs than compact-kernel waves the chip holds: 18 per CU)
-    const uint32_t piece = 65536u, parts = 1u;      // one 64 KiB piece from the middle of each payload (more or smaller pieces order no better)
+    uint32_t piece = 65536u, parts = 1u;            // one 64 KiB piece from the middle of each payload (more or smaller pieces order no better)
+#ifdef LZF_ANALYSIS      // LZF_PROBE="piece,parts": the cost probe's sample (A/B of the launch order's estimate)
+    { static const char* e = getenv("LZF_PROBE"); if (e) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 4096u && b >= 1u && b <= 16u) { piece = a; parts = b; } } }
+#endif
     const size_t n_probes = want_order ? (size_t)n_jobs * parts : 0u;
     const size_t probes_off = 256;                  // [queue of the rows variant][probe jobs][probe results][perm]
     const size_t res_off = probes_off + align_up(sizeof(lzf_compress_job) * n_probes, 256);
