@@ -363,7 +363,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                             if (lane == L3 + 1u) byte = off3;
                             if (lane == L3 + 2u) byte = off3 >> 8;
                             flush_ps();
-                            if (!DRY && lane < tot3) s.out[s.pos + lane] = (uint8_t)byte;
+                            ps_byte = byte; ps_pos = s.pos; ps_n = tot3;                   // (deferred like the common sequence's)
                             s.pos += tot3;
                             PCOUNT(pc_ext);
                             continue;
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 if (lane == 0u) byte = (L << 4) | extra;
                 if (lane == L + 1u) byte = dup_offset;
                 if (lane == L + 2u) byte = dup_offset >> 8;
-                if (!DRY && lane < total) s.out[s.pos + lane] = (uint8_t)byte;
+                ps_byte = byte; ps_pos = s.pos; ps_n = total;                              // (deferred like the straight path's; flush_ps() ran above)
                 s.pos += total;
                 PCOUNT(pc_tail_short);
                 CPHASE(3);
