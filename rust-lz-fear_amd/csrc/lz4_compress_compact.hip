@@ -46,7 +46,11 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
     // scratch word per lane: lanes with nothing to do aim their LDS accesses there instead of leaving the instruction (exec-mask
     // bookkeeping is scalar work, and the scalar unit is the bottleneck of this kernel)
     constexpr uint32_t kParBase = kSlots / 2, kScratch = kSlots / 2 + kSlots / 32;
+#ifdef LZF_DBG_LDS_PAD
+    __shared__ __attribute__((aligned(16))) uint32_t tab32[kSlots / 2 + kSlots / 32 + kWave + LZF_DBG_LDS_PAD / 4];      // occupancy experiment
+#else
     __shared__ __attribute__((aligned(16))) uint32_t tab32[kSlots / 2 + kSlots / 32 + kWave];
+#endif
     uint32_t* const par = tab32 + kParBase;
     uint16_t* const tab16 = reinterpret_cast<uint16_t*>(tab32);
     const uint32_t tab_a = lds_addr(tab32);
