@@ -14,7 +14,7 @@ __global__ void lzf_decompress_wave_kernel(const lzf_decompress_job* __restrict_
                                            lzf_job_result* __restrict__ results, uint32_t n_jobs, const uint32_t* __restrict__ perm);
 #endif
 template <int RING, int S, int TOKCAP, bool STAGE>
-__global__ void lzf_decompress_batched_kernel(const lzf_decompress_job* __restrict__ jobs,
+__global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(const lzf_decompress_job* __restrict__ jobs,
                                               lzf_job_result* __restrict__ results, uint32_t n_jobs, const uint32_t* __restrict__ perm);
 // Tuning variants of the batched kernel: X(name, ring bytes, region bytes, token-list entries, chunk staged in LDS).
 // LZF_DECOMPRESS_KERNEL=<name> selects one (A/B knob; every variant implements the same contract).
@@ -44,10 +44,12 @@ LZF_WINDOWED_VARIANTS(LZF_EXTW)
 #undef LZF_EXTW
 #endif
 // Producer / consumer pairs (lz4_decompress_paired.hip): X(name, ring bytes, region bytes, token-list entries).
+// (The launch bounds are repeated on the template DECLARATIONS of this header since round 4: hipcc takes a template kernel's
+//  attributes from its first declaration, and without them the instantiations were compiled for 1 024-thread workgroups.)
 struct seg_job;
 // done (optional): state array of the segmented pipeline; a job it finished (done[jid].done != 0) is skipped
 template <int RING, int S, int TOKCAP>
-__global__ void lzf_decompress_paired_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
+__global__ __launch_bounds__(128) void lzf_decompress_paired_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
                                              const uint32_t* __restrict__ perm, const seg_job* __restrict__ done);
 #ifdef LZF_ANALYSIS
 #define LZF_PAIRED_VARIANTS(X) \
@@ -148,18 +150,18 @@ __global__ void lzf_seg_tilesum_kernel(seg_ctx c);
 __global__ void lzf_seg_scan_kernel(seg_ctx c);
 __global__ void lzf_seg_records_kernel(seg_ctx c);
 template <int R>
-__global__ void lzf_seg_resolve_pair_kernel(seg_ctx c);
+__global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c);
 extern template __global__ void lzf_seg_resolve_pair_kernel<32768>(seg_ctx);
 extern template __global__ void lzf_seg_resolve_pair_kernel<65536>(seg_ctx);
 extern template __global__ void lzf_seg_resolve_pair_kernel<131072>(seg_ctx);
 template <int KIND>
-__global__ void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
+__global__ __launch_bounds__(64) void lzf_compress_wave_kernel(const lzf_compress_job* __restrict__ jobs,
                                          lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t skip_compact,
                                          const uint32_t* __restrict__ perm);
 extern template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U32>(const lzf_compress_job*, lzf_job_result*, uint32_t, uint32_t, const uint32_t*);
 extern template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U16>(const lzf_compress_job*, lzf_job_result*, uint32_t, uint32_t, const uint32_t*);
 template <bool DRY>
-__global__ void lzf_compress_compact_kernel(const lzf_compress_job* __restrict__ jobs,
+__global__ __launch_bounds__(64) void lzf_compress_compact_kernel(const lzf_compress_job* __restrict__ jobs,
                                             lzf_job_result* __restrict__ results, uint32_t n_jobs, const uint32_t* __restrict__ perm,
                                             uint32_t alone);
 extern template __global__ void lzf_compress_compact_kernel<false>(const lzf_compress_job*, lzf_job_result*, uint32_t, const uint32_t*, uint32_t);
