@@ -157,7 +157,11 @@ void lzf_frame_get_stats(lzf_frame_stats* st);
 /* The drivers keep their pinned slab and device scratch between calls (allocating gigabytes costs more than the
  * kernels); this gives everything back.  Calls are serialised per device (one slab per device). */
 void lzf_frame_release_scratch(void);
-void lzf_frame_set_host_threads(uint32_t n);      /* memcpy / hashing workers, 0 = default (12 on a large host) */
+/* Worker threads of the host staging (pageable <-> pinned copies, content hashes of long frames): n of them, 0 = default (12 on a
+ * large host), LZF_HOST_THREADS_NONE = none at all — the calling thread does every copy itself (no hidden host
+ * threads are REQUIRED; they are a throughput option).  The threads are created on first use and kept. */
+#define LZF_HOST_THREADS_NONE 0xFFFFFFFFu
+void lzf_frame_set_host_threads(uint32_t n);
 /* Device memory one pass of lzf_frame_decompress_many may use (0 = half of what is free): more frames than fit are
  * processed in several passes; a frame that does not fit alone gets status LZF_E_NO_MEMORY. */
 void lzf_frame_set_memory_budget(size_t bytes);

@@ -72,9 +72,23 @@ struct Staging::Pool {
         std::unique_lock<std::mutex> g(m);
         cv_done.wait(g, [this] { return pending == 0; });
     }
+    // wait for a condition a task establishes; the calling thread runs queued tasks meanwhile (with no worker threads at all —
+    // lzf_frame_set_host_threads(LZF_HOST_THREADS_NONE) — it runs every one of them, in order)
     template <class Pred> void wait_until(Pred p) {
-        std::unique_lock<std::mutex> g(m);
-        cv_done.wait(g, p);
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> g(m);
+                if (p()) return;
+                if (q.empty()) { cv_done.wait(g, [&] { return p() || !q.empty(); }); if (p()) return; }
+                if (!q.empty()) { f = std::move(q.front()); q.pop_front(); }
+            }
+            if (f) {
+                f();
+                { std::lock_guard<std::mutex> g(m); --pending; }
+                cv_done.notify_all();
+            }
+        }
     }
 };
 
@@ -93,11 +107,12 @@ Staging& Staging::get() {
 Staging::Pool* Staging::pool() {
     unsigned want = want_threads_;
     if (!want) { const unsigned hw = std::thread::hardware_concurrency(); want = hw >= 48 ? 12 : hw >= 8 ? hw / 4 : 2; }
+    if (want == kNoThreads) want = 0;                  // every staging copy and hash on the calling thread
     if (pool_ && pool_->th.size() != want) { delete pool_; pool_ = nullptr; }
     if (!pool_) pool_ = new Pool(want);
     return pool_;
 }
-void Staging::set_threads(unsigned n) { want_threads_ = n > 64 ? 64 : n; }
+void Staging::set_threads(unsigned n) { want_threads_ = n == 0xFFFFFFFFu ? kNoThreads : n > 64 ? 64 : n; }
 
 void Staging::release() {
     if (pin_) (void)hipHostFree(pin_);

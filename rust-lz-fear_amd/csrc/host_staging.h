@@ -62,6 +62,7 @@ public:
     struct Counters { uint64_t h2d_copies, d2h_copies, h2d_bytes, d2h_bytes; } counters = {0, 0, 0, 0};
 private:
     Pool* pool_ = nullptr;
+    static constexpr unsigned kNoThreads = 0xFFFFFFFFu;      // set_threads(LZF_HOST_THREADS_NONE): no worker threads
     unsigned want_threads_ = 0;
     int device_ = -1;
 };

@@ -11,7 +11,7 @@ import pytest
 import oracle_ffi as o
 import vectors
 import rust_lz_fear_amd  # noqa: F401
-from rust_lz_fear_amd import framed, synth
+from rust_lz_fear_amd import ffi, framed, synth
 
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -422,6 +422,27 @@ def test_compress_many_equals_one_frame_at_a_time(kw):
     assert len(frames) == len(datas)
     for d, f in zip(datas, frames):
         assert f == o.frame_compress(d, o.make_settings(**okw))[1], (len(d), kw.keys())
+
+
+def test_many_frames_without_any_worker_thread():
+    """"no hidden host threads required".  The staging's worker threads are a throughput option:
+    lzf_frame_set_host_threads(LZF_HOST_THREADS_NONE) makes the calling thread do every pageable <-> pinned copy (and hash)
+    itself; frames large enough for the piecewise staging path must come out byte-identical, both ways."""
+    L = ffi.lib()
+    mix = synth.silesia_mix(3 << 20, 28 << 20).tobytes()
+    datas = [mix[: 9 << 20], mix[9 << 20: 20 << 20], mix[20 << 20: 25 << 20], b"", mix[:70_000]]
+    g, okw = settings_pair(block_size=1 << 20)
+    try:
+        L.lzf_frame_set_host_threads(0xFFFFFFFF)
+        frames = g.compress_many(datas)
+        got = framed.decompress_frames(frames, caps=[len(d) + 64 for d in datas])
+    finally:
+        L.lzf_frame_set_host_threads(0)
+    for d, f, (rc, out) in zip(datas, frames, got):
+        assert f == o.frame_compress(d, o.make_settings(**okw))[1], len(d)
+        assert rc == 0 and out == d, len(d)
+    again = g.compress_many(datas)                      # back on the default pool: the same frames
+    assert again == frames
 
 
 def test_decompress_many_equals_one_frame_at_a_time():
