@@ -67,10 +67,17 @@ __device__ __forceinline__ void put_match_lds(uint32_t dst, uint32_t srca, uint3
 // Same, source in global memory (unaligned loads; reads exactly [g, g+n)).
 __device__ __forceinline__ void put_small_glb(uint32_t dst, cgu8* g, uint32_t n) {
     if (n > 32u) {
-        const uint64_t a0 = ld8(g), a1 = ld8(g + 8u), a2 = ld8(g + 16u), a3 = ld8(g + 24u);
-        const uint64_t b0 = ld8(g + n - 32u), b1 = ld8(g + n - 24u), b2 = ld8(g + n - 16u), b3 = ld8(g + n - 8u);
-        lds_st64(dst, a0); lds_st64(dst + 8u, a1); lds_st64(dst + 16u, a2); lds_st64(dst + 24u, a3);
-        lds_st64(dst + n - 32u, b0); lds_st64(dst + n - 24u, b1); lds_st64(dst + n - 16u, b2); lds_st64(dst + n - 8u, b3);
+        // (two halves one after the other: eight 8-byte values in flight at once were the register peak of the copy stage, and
+        //  the case is rare — a literal run or far match of 33..64 bytes that is not in the staged chunk)
+        {
+            const uint64_t a0 = ld8(g), a1 = ld8(g + 8u), a2 = ld8(g + 16u), a3 = ld8(g + 24u);
+            lds_st64(dst, a0); lds_st64(dst + 8u, a1); lds_st64(dst + 16u, a2); lds_st64(dst + 24u, a3);
+        }
+        asm volatile("" ::: "memory");
+        {
+            const uint64_t b0 = ld8(g + n - 32u), b1 = ld8(g + n - 24u), b2 = ld8(g + n - 16u), b3 = ld8(g + n - 8u);
+            lds_st64(dst + n - 32u, b0); lds_st64(dst + n - 24u, b1); lds_st64(dst + n - 16u, b2); lds_st64(dst + n - 8u, b3);
+        }
     } else if (n >= 8u) {
         const bool big = n > 16u;
         const uint64_t v0 = ld8(g), v3 = ld8(g + n - 8u);
