@@ -98,6 +98,7 @@ extern "C" {
     pub fn lzf_xxh32_batch_host(ptrs: *const *const u8, lens: *const u64, out: *mut u32, n: u32) -> c_int;
     pub fn lzf_decompress_batch_sized(d_jobs: *const lzf_decompress_job, d_results: *mut lzf_job_result, n_jobs: u32, max_input_len: u64, hip_stream: *mut c_void) -> c_int;
     pub fn lzf_last_decompress_launch() -> *const c_char;
+    pub fn lzf_last_compress_launch() -> *const c_char;
     // EncoderTable::replace / ::offset on host tables (src/raw/compress/mod.rs:64-74, :88-99)
     pub fn lzf_table_replace_host(table: *mut c_void, table_kind: u32, input: *const u8, input_len: u64, pos: u64, previous: *mut u64) -> c_int;
     pub fn lzf_table_offset_host(table: *mut c_void, table_kind: u32, add: u64) -> c_int;

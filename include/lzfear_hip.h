@@ -148,6 +148,10 @@ int lzf_decompress_batch_sized(const lzf_decompress_job* d_jobs, lzf_job_result*
 /* Diagnostic: the kernels the calling thread's last lzf_decompress_batch launched (the batch size picks them: the
  * segmented pipeline — one block decoded by many wavefronts — up to four blocks per CU, one workgroup per block beyond). */
 const char* lzf_last_decompress_launch(void);
+/* The same for the calling thread's last lzf_compress_batch: "lzf_compress_team_kernel" (the latency class: no more jobs than
+ * compute units, a team of three wavefronts and a CU's LDS per block) or "lzf_compress_compact_kernel" (one wavefront per
+ * block, 18 per CU), plus the general kernels that ran beside it for U16 / writable-table jobs. */
+const char* lzf_last_compress_launch(void);
 
 /* EncoderTable helpers on device tables.
  * lzf_table_seed_from_dictionary: the template-table loop of src/framed/compress.rs:202-211

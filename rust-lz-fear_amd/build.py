@@ -20,12 +20,12 @@ LIB_PATH = os.environ.get("LZF_LIB_PATH") or os.path.join(PKG_DIR, "liblzfear_hi
 ANALYSIS_LIB_PATH = os.path.join(PKG_DIR, "liblzfear_hip_analysis.so")
 
 PRODUCT_HIP = ["capi.hip", "lz4_decompress_batched.hip", "lz4_decompress_paired.hip", "lz4_decompress_seg.hip", "lz4_compress.hip",
-               "lz4_compress_compact.hip", "aux_kernels.hip"]
+               "lz4_compress_compact.hip", "lz4_compress_team.hip", "aux_kernels.hip"]
 ANALYSIS_HIP = ["analysis/lz4_decompress.hip", "analysis/lz4_decompress_windowed.hip", "analysis/lz4_decompress_v6.hip", "analysis/lz4_compress_rows.hip"]
 CXX_SOURCES = ["frame.cpp", "host_staging.cpp"]
 HEADERS = ["kernels.h", "lzf_device.h", "lz4_decompress_batch_phase.inc", "lz4_decompress_parse_phase.inc",
            "analysis/lz4_decompress_copy3.inc", "analysis/capi_analysis.inc",
-           "analysis/lz4_decompress_gwalk_phase.inc", "lzf_copy_helpers.h", "lzf_parse_helpers.h", "lzf_compress_common.h", "lzf_simt.h", "analysis/lz4_compress_rows.inc",
+           "analysis/lz4_decompress_gwalk_phase.inc", "lzf_copy_helpers.h", "lzf_parse_helpers.h", "lzf_compress_common.h", "lzf_simt.h", "analysis/lz4_compress_rows.inc", "lz4_compress_team.inc",
            "host_staging.h",
            os.path.join(ROOT, "include", "lzfear_hip.h"), os.path.join(ROOT, "include", "lzfear_frame.h")]
 

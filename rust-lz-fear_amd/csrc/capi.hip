@@ -15,7 +15,8 @@
 namespace {
 
 thread_local std::string g_last_error;
-thread_local const char* g_last_decompress = "";      // what the last lzf_decompress_batch of this thread launched
+thread_local const char* g_last_decompress = "";
+thread_local const char* g_last_compress = "";        // ... and the last lzf_compress_batch      // what the last lzf_decompress_batch of this thread launched
 
 int fail_hip(hipError_t e, const char* what) {
     char buf[256];
@@ -102,6 +103,8 @@ constexpr auto k_compact = lzf::lzf_compress_compact_kernel<false>;
 constexpr auto k_compact_dry = lzf::lzf_compress_compact_kernel<true>;
 constexpr auto k_general_u32 = lzf::lzf_compress_wave_kernel<LZF_TABLE_U32>;
 constexpr auto k_general_u16 = lzf::lzf_compress_wave_kernel<LZF_TABLE_U16>;
+constexpr uint32_t kTeamLds = 151936u;      // LDS of one workgroup of lzf_compress_team_kernel (lz4_compress_team.inc: team::kLdsWords * 4)
+constexpr uint32_t kTeamRounds = 1u;        // batches of up to this many jobs per CU take the team kernel
 
 // ---- the segmented pipeline (lz4_decompress_seg.hip): geometry, scratch, launches ------------------------------------
 constexpr uint32_t kSegMaxIn = 4u * 1024u * 1024u + 32u * 1024u;     // a 4 MiB block at LZ4's worst case, rounded up
@@ -231,6 +234,7 @@ extern "C" {
 int lzf_abi_version(void) { return LZFEAR_ABI_VERSION; }
 const char* lzf_last_error(void) { return g_last_error.c_str(); }
 const char* lzf_last_decompress_launch(void) { return g_last_decompress; }
+const char* lzf_last_compress_launch(void) { return g_last_compress; }
 int lzf_device_count(void) { return ensure_device(); }
 
 // Launch order (both batch calls): a batch of more jobs than the chip holds at once runs longest job first, or the launch
@@ -249,13 +253,21 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
     // kernel that does not own a job reads the job and returns) unless the caller vouches for the batch with
     // LZF_KINDS_U32_FRESH_ONLY.
     uint32_t use_compact = 1u, use_order = 1u, use_rows = 0u;
+    // The latency class: a call with no more jobs than the chip has compute units gives every compact-table job a CU of its own —
+    // lzf_compress_team_kernel, three wavefronts per block, input window and table in LDS (lz4_compress_team.inc) — instead of a lone
+    // wavefront of the compact kernel.  (Needs a CU's whole LDS; LZF_COMPRESS_TEAM_MAX in the analysis flavour moves the threshold.)
+    uint32_t team_max = geometry().lds >= kTeamLds ? kTeamRounds * cu_count() : 0u;
 #ifdef LZF_ANALYSIS
     // LZF_COMPRESS_KERNEL = general (everything on lzf_compress_wave_kernel) | rows (round 4's four-blocks-per-wavefront kernel,
     // analysis/lz4_compress_rows.hip: measured slower than the compact kernel at every batch size, kept as a variant; profiles/r04_compress_rows.txt)
     { static const uint32_t which = [] { const char* e = getenv("LZF_COMPRESS_KERNEL"); return !e ? 0u : !strcmp(e, "general") ? 1u : !strcmp(e, "rows") ? 2u : 0u; }();
       static const uint32_t order = analysis_order("LZF_COMPRESS_ORDER");
-      use_compact = which == 1u ? 0u : 1u; use_rows = which == 2u ? 1u : 0u; use_order = order; }
+      use_compact = which == 1u ? 0u : 1u; use_rows = which == 2u ? 1u : 0u; use_order = order;
+      static const long tm = [] { const char* e = getenv("LZF_COMPRESS_TEAM_MAX"); return e ? atol(e) : -1L; }();
+      if (tm >= 0 && geometry().lds >= kTeamLds) team_max = (uint32_t)tm;
+      if (which != 0u) team_max = 0u; }
 #endif
+    const bool use_team = use_compact && n_jobs <= team_max;
     const bool fresh_only = use_compact && (table_kinds & LZF_KINDS_U32_FRESH_ONLY);
     uint32_t* perm = nullptr;
     AsyncScratch scratch_owner; scratch_owner.st = st;
@@ -301,12 +313,17 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
             rows_done = true;
         }
 #endif
-        if (use_compact && !rows_done) LAUNCH(k_compact, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, fresh_only ? 1u : 0u);
+        if (use_team && !rows_done) LAUNCH(lzf::lzf_compress_team_kernel, dim3(n_jobs), dim3(192), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, fresh_only ? 1u : 0u);
+        else if (use_compact && !rows_done) LAUNCH(k_compact, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, fresh_only ? 1u : 0u);
 #endif
         if (!fresh_only) LAUNCH(k_general_u32, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, use_compact, (const uint32_t*)perm);
     }
     if (table_kinds & LZF_KINDS_U16)
         LAUNCH(k_general_u16, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, 0u, (const uint32_t*)perm);
+    g_last_compress = !(table_kinds & LZF_KINDS_U32) ? "lzf_compress_wave_kernel<U16>"
+                    : !use_compact ? "lzf_compress_wave_kernel (analysis: general)" : use_rows ? "lzf_compress_rows_kernel (analysis)"
+                    : use_team ? (fresh_only ? "lzf_compress_team_kernel" : "lzf_compress_team_kernel + lzf_compress_wave_kernel")
+                               : (fresh_only ? "lzf_compress_compact_kernel" : "lzf_compress_compact_kernel + lzf_compress_wave_kernel");
     HIP_TRY(scratch_owner.release());
     return LZF_OK;
 }

@@ -166,6 +166,9 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(const lzf_comp
                                             uint32_t alone);
 extern template __global__ void lzf_compress_compact_kernel<false>(const lzf_compress_job*, lzf_job_result*, uint32_t, const uint32_t*, uint32_t);
 extern template __global__ void lzf_compress_compact_kernel<true>(const lzf_compress_job*, lzf_job_result*, uint32_t, const uint32_t*, uint32_t);
+// the latency class (lz4_compress_team.hip / .inc; round 5): one block per CU, searcher / emitter / feeder wavefronts, input ring and table in LDS
+__global__ void lzf_compress_team_kernel(const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
+                                         const uint32_t* __restrict__ perm, uint32_t alone);
 #ifdef LZF_ANALYSIS
 // four blocks per wavefront, persistent waves (analysis/lz4_compress_rows.hip / .inc; round 4, analysis variant): the compact-table jobs of a
 // batch; queue = next position of perm[] (or of the job array) to hand out, zero before the launch; rows_active = rows of a wave that take jobs

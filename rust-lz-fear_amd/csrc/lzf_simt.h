@@ -48,6 +48,48 @@ struct SimtGpu {
             v0 = r0; v1 = r1; v2 = r2;
         }
     }
+    // ---- round 5: what a TEAM of wavefronts per block needs (lz4_compress_team.inc): the wave's index in the workgroup, values of a
+    //      uniform lane, byte-addressed LDS reads at any alignment with several in flight, the min-lane tag protocol as one step,
+    //      16-byte LDS accesses, flag words between the waves of a workgroup (explicit ds_* instructions: a volatile LDS pointer is a
+    //      generic pointer to hipcc, i.e. FLAT accesses), a workgroup barrier
+    LZF_SIMT_FN uint32_t wave() const { return threadIdx.x >> 6; }
+    LZF_SIMT_FN uint32_t readlane(uint32_t v, uint32_t src) const { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }   // src uniform
+    LZF_SIMT_FN uint64_t lds_rd64bu(uint32_t byte) const {
+        uint64_t r; asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(lds_a + byte) : "memory"); return r;
+    }
+    LZF_SIMT_FN uint32_t lds_rd32b(bool p, uint32_t byte) const {
+        uint32_t r = 0; if (p) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(lds_a + byte) : "memory"); return r;
+    }
+    LZF_SIMT_FN void lds_rd8x2u(uint32_t b0, uint32_t b1, uint32_t& v0, uint32_t& v1) const {
+        asm volatile("ds_read_u8 %0, %2\n\tds_read_u8 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(lds_a + b0), "v"(lds_a + b1) : "memory");
+    }
+    LZF_SIMT_FN uint32_t lds_rd8(bool p, uint32_t byte) const {
+        uint32_t r = 0; if (p) asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(lds_a + byte) : "memory"); return r;
+    }
+    // old = lds[w]; lds[w] = MARK; lds[w] = min(lds[w], tag); first = lds[w]  (one wave's LDS accesses execute in order)
+    LZF_SIMT_FN void lds_tag(uint32_t w, uint32_t tag, uint32_t& old, uint32_t& first) const {
+        asm volatile("ds_read_b32 %0, %2\n\tds_write_b32 %2, %3\n\tds_min_u32 %2, %4\n\tds_read_b32 %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(old), "=&v"(first) : "v"(lds_a + 4u * w), "v"(0xFFFFFFFFu), "v"(tag) : "memory");
+    }
+    LZF_SIMT_FN void lds_wr32a(uint32_t w, uint32_t v) const { asm volatile("ds_write_b32 %0, %1" ::"v"(lds_a + 4u * w), "v"(v) : "memory"); }
+    LZF_SIMT_FN u32x4 lds_rd128(uint32_t w) const {
+        u32x4 r; asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(lds_a + 4u * w) : "memory"); return r;
+    }
+    LZF_SIMT_FN void lds_wr128a(bool p, uint32_t w, u32x4 v) const { if (p) asm volatile("ds_write_b128 %0, %1" ::"v"(lds_a + 4u * w), "v"(v) : "memory"); }
+    LZF_SIMT_FN uint32_t flag_rd(uint32_t w) const {
+        uint32_t r; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(lds_a + 4u * w) : "memory"); return rfl(r);
+    }
+    LZF_SIMT_FN void flag_rd2(uint32_t w, uint32_t& a, uint32_t& c) const {          // two adjacent flag words, w even
+        uint64_t r; asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(lds_a + 4u * w) : "memory");
+        a = rfl((uint32_t)r); c = rfl((uint32_t)(r >> 32));
+    }
+    LZF_SIMT_FN void flag_wr(uint32_t w, uint32_t v) const { if (lane() == 0u) asm volatile("ds_write_b32 %0, %1" ::"v"(lds_a + 4u * w), "v"(v) : "memory"); }
+    LZF_SIMT_FN void flag_wr2(uint32_t w, uint32_t v0, uint32_t v1) const {
+        if (lane() == 0u) asm volatile("ds_write_b64 %0, %1" ::"v"(lds_a + 4u * w), "v"(((uint64_t)v1 << 32) | v0) : "memory");
+    }
+    LZF_SIMT_FN void sleep() const { __builtin_amdgcn_s_sleep(2); }
+    LZF_SIMT_FN void barrier() const { __syncthreads(); }
+    LZF_SIMT_FN void lds_fence() const { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
     LZF_SIMT_FN uint32_t atomic_inc(uint32_t* q) const { return atomicAdd(q, 1u); }
     LZF_SIMT_FN uint64_t clock() const { return (uint64_t)clock64(); }
     LZF_SIMT_FN void keep(uint32_t v) const { asm volatile("" ::"v"(v)); }      // the value counts as used (a load made only to warm the caches)
@@ -106,16 +148,27 @@ struct EmuWave {
     bool finished[64];
     uint32_t cur;
     uint64_t n_sync;                // lock-step points executed (a cost figure for the tests)
+    // round 5 (teams of wavefronts, tests/emu/emu_compress_team.cpp): the LDS the primitives address (this wave's own array or the
+    // workgroup's), the wave's index, the next wave of the workgroup (a ring; a lone wave points at itself), barrier bookkeeping
+    uint32_t* L;
+    uint32_t wave_id;
+    EmuWave* next;
+    uint32_t* bar_count;            // arrivals at workgroup barriers so far (shared by the waves of a workgroup)
+    uint32_t n_waves;
+    uint32_t bar_gen;               // barriers this wave has passed
 };
+// the wave whose lanes are running (a fiber that starts reads its lane number from emu_current()->cur)
+static inline EmuWave*& emu_current() { static EmuWave* w = nullptr; return w; }
 struct SimtEmu {
     EmuWave* w;
     uint32_t my;
     uint32_t lane() const { return my; }
-    void sync() const {             // every lane reaches the same primitive before any lane goes on
+    // every lane reaches the same primitive before any lane goes on; behind the last lane of a wave the next wave of the workgroup
+    // runs ITS lanes up to their next primitive (one fixed interleaving of the waves, deterministic)
+    void sync() const {
         w->n_sync++;
-        const uint32_t nxt = (my + 1u) & 63u;
-        w->cur = nxt;
-        lzf_emu_switch(&w->sp[my], w->sp[nxt]);
+        if (my + 1u < 64u) { w->cur = my + 1u; lzf_emu_switch(&w->sp[my], w->sp[my + 1u]); }
+        else { EmuWave* nx = w->next; nx->cur = 0; emu_current() = nx; lzf_emu_switch(&w->sp[my], nx->sp[0]); }
     }
     unsigned long long ballot(bool p) const {
         sync(); w->xchg[my] = p ? 1u : 0u; sync();
@@ -124,18 +177,45 @@ struct SimtEmu {
     }
     bool any(bool p) const { return ballot(p) != 0ull; }
     uint32_t bperm(uint32_t src_lane, uint32_t v) const { sync(); w->xchg[my] = v; sync(); return (uint32_t)w->xchg[src_lane & 63u]; }
-    uint32_t lds_rd32(bool p, uint32_t i) const { sync(); return p ? w->lds[i] : 0u; }
-    void lds_wr32(bool p, uint32_t i, uint32_t v) const { sync(); if (p) w->lds[i] = v; }
-    void lds_min32(bool p, uint32_t i, uint32_t v) const { sync(); if (p && v < w->lds[i]) w->lds[i] = v; }
-    void lds_mskor32(bool p, uint32_t i, uint32_t mask, uint32_t val) const { sync(); if (p) w->lds[i] = (w->lds[i] & ~mask) | val; }
+    uint32_t lds_rd32(bool p, uint32_t i) const { sync(); return p ? w->L[i] : 0u; }
+    void lds_wr32(bool p, uint32_t i, uint32_t v) const { sync(); if (p) w->L[i] = v; }
+    void lds_min32(bool p, uint32_t i, uint32_t v) const { sync(); if (p && v < w->L[i]) w->L[i] = v; }
+    void lds_mskor32(bool p, uint32_t i, uint32_t mask, uint32_t val) const { sync(); if (p) w->L[i] = (w->L[i] & ~mask) | val; }
     uint32_t lds_rd32u(uint32_t i) const { return lds_rd32(true, i); }
     void lds_wr32u(uint32_t i, uint32_t v) const { lds_wr32(true, i, v); }
     void lds_min32u(uint32_t i, uint32_t v) const { lds_min32(true, i, v); }
     void lds_mskor32u(uint32_t i, uint32_t mask, uint32_t val) const { lds_mskor32(true, i, mask, val); }
-    void lds_wr128(bool p, uint32_t i, u32x4 v) const { sync(); if (p) memcpy(&w->lds[i], &v, 16); }
+    void lds_wr128(bool p, uint32_t i, u32x4 v) const { sync(); if (p) memcpy(&w->L[i], &v, 16); }
     void lds_rd64b3(bool p, uint32_t b0, uint32_t b1, uint32_t b2, uint64_t& v0, uint64_t& v1, uint64_t& v2) const {
         sync();
-        if (p) { const uint8_t* l = (const uint8_t*)w->lds; memcpy(&v0, l + b0, 8); memcpy(&v1, l + b1, 8); memcpy(&v2, l + b2, 8); }
+        if (p) { const uint8_t* l = (const uint8_t*)w->L; memcpy(&v0, l + b0, 8); memcpy(&v1, l + b1, 8); memcpy(&v2, l + b2, 8); }
+    }
+    // ---- round 5 (see SimtGpu)
+    uint32_t wave() const { return w->wave_id; }
+    uint32_t readlane(uint32_t v, uint32_t src) const { return bperm(src, v); }
+    uint64_t lds_rd64bu(uint32_t byte) const { sync(); uint64_t v; memcpy(&v, (const uint8_t*)w->L + byte, 8); return v; }
+    uint32_t lds_rd32b(bool p, uint32_t byte) const { sync(); uint32_t v = 0; if (p) memcpy(&v, (const uint8_t*)w->L + byte, 4); return v; }
+    void lds_rd8x2u(uint32_t b0, uint32_t b1, uint32_t& v0, uint32_t& v1) const { sync(); const uint8_t* l = (const uint8_t*)w->L; v0 = l[b0]; v1 = l[b1]; }
+    uint32_t lds_rd8(bool p, uint32_t byte) const { sync(); return p ? ((const uint8_t*)w->L)[byte] : 0u; }
+    void lds_tag(uint32_t i, uint32_t tag, uint32_t& old, uint32_t& first) const {
+        old = lds_rd32(true, i); lds_wr32(true, i, 0xFFFFFFFFu); lds_min32(true, i, tag); first = lds_rd32(true, i);
+    }
+    void lds_wr32a(uint32_t i, uint32_t v) const { lds_wr32(true, i, v); }
+    u32x4 lds_rd128(uint32_t i) const { sync(); u32x4 v; memcpy(&v, &w->L[i], 16); return v; }
+    void lds_wr128a(bool p, uint32_t i, u32x4 v) const { lds_wr128(p, i, v); }
+    uint32_t flag_rd(uint32_t i) const { sync(); return w->L[i]; }
+    void flag_rd2(uint32_t i, uint32_t& a, uint32_t& c) const { sync(); a = w->L[i]; c = w->L[i + 1u]; }
+    void flag_wr(uint32_t i, uint32_t v) const { sync(); if (my == 0u) w->L[i] = v; }
+    void flag_wr2(uint32_t i, uint32_t v0, uint32_t v1) const { sync(); if (my == 0u) { w->L[i] = v0; w->L[i + 1u] = v1; } }
+    void sleep() const { sync(); }
+    void lds_fence() const {}
+    // all waves of the workgroup: the lanes of a wave test the counter at the same lock-step point (other waves only run between
+    // two rotations of this wave), so they leave together
+    void barrier() const {
+        sync();
+        if (my == 0u) { ++*w->bar_count; ++w->bar_gen; }
+        sync();
+        for (;;) { const bool ok = *w->bar_count >= w->bar_gen * w->n_waves; sync(); if (ok) break; }
     }
     uint32_t atomic_inc(uint32_t* q) const { return (*q)++; }
     uint64_t clock() const { return 0; }

@@ -67,7 +67,7 @@ class FrameInfo(C.Structure):
 
 EXPORTS = [
     "lzf_abi_version", "lzf_last_error", "lzf_device_count", "lzf_compress_batch",
-    "lzf_decompress_batch", "lzf_decompress_batch_sized", "lzf_last_decompress_launch", "lzf_table_replace_host", "lzf_table_offset_host", "lzf_compress2_host_writer", "lzf_table_seed_from_dictionary", "lzf_table_offset", "lzf_table_offset_batch",
+    "lzf_decompress_batch", "lzf_decompress_batch_sized", "lzf_last_decompress_launch", "lzf_last_compress_launch", "lzf_table_replace_host", "lzf_table_offset_host", "lzf_compress2_host_writer", "lzf_table_seed_from_dictionary", "lzf_table_offset", "lzf_table_offset_batch",
     "lzf_chain_decompress_step",
     "lzf_xxh32_batch", "lzf_copy_ranges", "lzf_compress_batch_host", "lzf_decompress_batch_host", "lzf_xxh32_batch_host",
 ]
@@ -116,6 +116,7 @@ def lib():
         L = C.CDLL(path)
         L.lzf_last_error.restype = C.c_char_p
         L.lzf_last_decompress_launch.restype = C.c_char_p
+        L.lzf_last_compress_launch.restype = C.c_char_p
         L.lzf_compress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
         L.lzf_decompress_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
         L.lzf_decompress_batch_sized.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p]

@@ -85,6 +85,7 @@ extern "C" int lzf_emu_compress_rows(const lzf_compress_job* jobs, lzf_job_resul
     for (uint32_t wv = 0; wv < n_waves && rc == 0; ++wv) {
         memset(w, 0xA5, sizeof(EmuWave));                     // LDS starts as garbage, like on the device
         w->n_sync = 0; w->cur = 0;
+        w->L = w->lds; w->next = w; w->wave_id = 0; w->n_waves = 1; w->bar_gen = 0; w->bar_count = &w->bar_gen;     // (a lone wave: its own LDS array, no barriers)
         for (uint32_t i = 0; i < 64; ++i) { w->sp[i] = make_stack(stacks + kStack * i); w->finished[i] = false; }
         g_wave = w;
         lzf_emu_switch(&w->sched_sp, w->sp[0]);
