@@ -103,7 +103,7 @@ constexpr auto k_compact = lzf::lzf_compress_compact_kernel<false>;
 constexpr auto k_compact_dry = lzf::lzf_compress_compact_kernel<true>;
 constexpr auto k_general_u32 = lzf::lzf_compress_wave_kernel<LZF_TABLE_U32>;
 constexpr auto k_general_u16 = lzf::lzf_compress_wave_kernel<LZF_TABLE_U16>;
-constexpr uint32_t kTeamLds = 151936u;      // LDS of one workgroup of lzf_compress_team_kernel (lz4_compress_team.inc: team::kLdsWords * 4)
+constexpr uint32_t kTeamLds = 163840u;      // LDS of one workgroup of lzf_compress_team_kernel (lz4_compress_team.inc: team::kLdsWords * 4)
 constexpr uint32_t kTeamRounds = 1u;        // batches of up to this many jobs per CU take the team kernel
 
 // ---- the segmented pipeline (lz4_decompress_seg.hip): geometry, scratch, launches ------------------------------------

@@ -1,13 +1,13 @@
 // lz4_compress_team.hip — the latency class of lzf_compress_batch for gfx950: one block per compute unit, a team of three wavefronts
 // (searcher, emitter, feeder), the input window and the position table in LDS.  The kernel body is lz4_compress_team.inc (written
 // against lzf_simt.h so that the CPU suite runs the same source under a lock-step emulator); this file instantiates it with the
-// gfx950 primitives.  148 KiB of LDS per workgroup: one workgroup per CU.
+// gfx950 primitives.  160 KiB of LDS per workgroup (all of a CU's): one workgroup per CU.
 #include "lz4_compress_team.inc"
 #include "kernels.h"
 
 namespace lzf {
 
-static_assert(team::kLdsWords * 4u == 151936u, "capi.hip's kTeamLds (the dispatch's LDS requirement) is this number");
+static_assert(team::kLdsWords * 4u == 163840u, "capi.hip's kTeamLds (the dispatch's LDS requirement) is this number");
 
 __global__ __launch_bounds__(192) void lzf_compress_team_kernel(const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results,
                                                                 uint32_t n_jobs, const uint32_t* __restrict__ perm, uint32_t alone) {

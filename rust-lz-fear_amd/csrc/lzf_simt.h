@@ -87,6 +87,37 @@ struct SimtGpu {
     LZF_SIMT_FN void flag_wr2(uint32_t w, uint32_t v0, uint32_t v1) const {
         if (lane() == 0u) asm volatile("ds_write_b64 %0, %1" ::"v"(lds_a + 4u * w), "v"(((uint64_t)v1 << 32) | v0) : "memory");
     }
+    // ---- the searcher's straight path (lz4_compress_team.inc "turbo"): byte offsets into the LDS array
+    // two bytes and 8 bytes at any alignment, one round trip
+    LZF_SIMT_FN void lds_rd8x2_64u(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t& v0, uint32_t& v1, uint64_t& v2) const {
+        asm volatile("ds_read_u8 %0, %3\n\tds_read_u8 %1, %4\n\tds_read_b64 %2, %5\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(lds_a + b0), "v"(lds_a + b1), "v"(lds_a + b2) : "memory");
+    }
+    // LDS byte ADDRESS of the U32Table slot of the 8 bytes v8 (mod.rs:41-51; the arithmetic of simt_hash5), the table at the 16 KiB-aligned
+    // address tab_addr (a VGPR: VOP3 takes one scalar operand on gfx9): the slot's byte offset is bits 26..39 of v * K with the low two cleared
+    LZF_SIMT_FN uint32_t hash5_slot_addr(uint64_t v8, uint32_t tab_addr) const {
+        const uint32_t xl = (uint32_t)v8, xh = (uint32_t)(v8 >> 32);
+        uint32_t t, u, r; uint64_t p;
+        asm("v_and_b32 %0, 0xff, %3\n\tv_mul_u32_u24 %0, 0xcf, %0\n\tv_and_b32 %1, 0xff, %4\n\tv_mad_u32_u24 %0, %1, %5, %0\n\t"
+            "v_mad_u64_u32 %2, vcc, %3, %6, 0"
+            : "=&v"(t), "=&v"(u), "=&v"(p) : "v"(xl), "v"(xh), "s"(0xBBu), "s"(0x1BBCDCBBu) : "vcc");
+        const uint32_t hi = (uint32_t)(p >> 32) + t;
+        asm("v_alignbit_b32 %0, %1, %2, 26\n\tv_and_or_b32 %0, %0, %3, %4" : "=&v"(r) : "v"(hi), "v"((uint32_t)p), "s"(0x3FFCu), "v"(tab_addr));
+        return r;
+    }
+    LZF_SIMT_FN uint32_t lds_byte_addr(uint32_t byte) const { return lds_a + byte; }
+    // the tag protocol and plain stores on byte ADDRESSES (hash5_slot_addr / lds_byte_addr)
+    LZF_SIMT_FN void lds_tag_at(uint32_t addr, uint32_t tag, uint32_t& old, uint32_t& first) const {
+        asm volatile("ds_read_b32 %0, %2\n\tds_write_b32 %2, %3\n\tds_min_u32 %2, %4\n\tds_read_b32 %1, %2\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&v"(old), "=&v"(first) : "v"(addr), "v"(0xFFFFFFFFu), "v"(tag) : "memory");
+    }
+    LZF_SIMT_FN void lds_wr32_at(uint32_t addr, uint32_t v) const { asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory"); }
+    // lane 0 alone writes a 16-byte descriptor and, behind it, two adjacent flag words.  All 64 lanes must be active at the call
+    // (the searcher's control flow is wave-uniform): EXEC is set to lane 0 and back to all lanes around the two stores.
+    LZF_SIMT_FN void push16_flag2(uint32_t desc_byte, u32x4 d, uint32_t flag_byte, uint32_t f0, uint32_t f1) const {
+        asm volatile("s_mov_b64 exec, 1\n\tds_write_b128 %0, %1\n\tds_write_b64 %2, %3\n\ts_mov_b64 exec, -1"
+                     ::"v"(lds_a + desc_byte), "v"(d), "v"(lds_a + flag_byte), "v"(((uint64_t)f1 << 32) | f0) : "memory");
+    }
     LZF_SIMT_FN void sleep() const { __builtin_amdgcn_s_sleep(2); }
     LZF_SIMT_FN void barrier() const { __syncthreads(); }
     LZF_SIMT_FN void lds_fence() const { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -207,6 +238,16 @@ struct SimtEmu {
     void flag_rd2(uint32_t i, uint32_t& a, uint32_t& c) const { sync(); a = w->L[i]; c = w->L[i + 1u]; }
     void flag_wr(uint32_t i, uint32_t v) const { sync(); if (my == 0u) w->L[i] = v; }
     void flag_wr2(uint32_t i, uint32_t v0, uint32_t v1) const { sync(); if (my == 0u) { w->L[i] = v0; w->L[i + 1u] = v1; } }
+    void lds_rd8x2_64u(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t& v0, uint32_t& v1, uint64_t& v2) const {
+        sync(); const uint8_t* l = (const uint8_t*)w->L; v0 = l[b0]; v1 = l[b1]; memcpy(&v2, l + b2, 8);
+    }
+    uint32_t hash5_slot_addr(uint64_t v8, uint32_t tab_addr) const { return tab_addr + 4u * simt_hash5(v8); }
+    uint32_t lds_byte_addr(uint32_t byte) const { return byte; }
+    void lds_tag_at(uint32_t addr, uint32_t tag, uint32_t& old, uint32_t& first) const { lds_tag(addr >> 2, tag, old, first); }
+    void lds_wr32_at(uint32_t addr, uint32_t v) const { lds_wr32(true, addr >> 2, v); }
+    void push16_flag2(uint32_t desc_byte, u32x4 d, uint32_t flag_byte, uint32_t f0, uint32_t f1) const {
+        sync(); if (my == 0u) { memcpy((uint8_t*)w->L + desc_byte, &d, 16); w->L[flag_byte >> 2] = f0; w->L[(flag_byte >> 2) + 1u] = f1; }
+    }
     void sleep() const { sync(); }
     void lds_fence() const {}
     // all waves of the workgroup: the lanes of a wave test the counter at the same lock-step point (other waves only run between

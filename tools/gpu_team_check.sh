@@ -11,3 +11,5 @@ for c in 1 5; do
   LZF_LIB_PATH=$A LZF_COMPRESS_TEAM_MAX=0 timeout 300 python tools/time_compress.py $c 3 >> $L 2>&1
 done
 grep -v "amdgpu.ids" $L
+D=$(ls rust-lz-fear_amd/liblzfear_hip_c6c2f81bec.so 2>/dev/null)
+if [ -n "$D" ]; then LZF_LIB_PATH=$D timeout 300 python tools/team_stats.py > gpurun_out/team_stats.log 2>&1; grep -v amdgpu.ids gpurun_out/team_stats.log | head -12; fi
