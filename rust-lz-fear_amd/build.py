@@ -21,11 +21,11 @@ ANALYSIS_LIB_PATH = os.path.join(PKG_DIR, "liblzfear_hip_analysis.so")
 
 PRODUCT_HIP = ["capi.hip", "lz4_decompress_batched.hip", "lz4_decompress_paired.hip", "lz4_decompress_seg.hip", "lz4_compress.hip",
                "lz4_compress_compact.hip", "lz4_compress_team.hip", "aux_kernels.hip"]
-ANALYSIS_HIP = ["analysis/lz4_decompress.hip", "analysis/lz4_decompress_windowed.hip", "analysis/lz4_decompress_v6.hip", "analysis/lz4_compress_rows.hip"]
+ANALYSIS_HIP = ["analysis/lz4_decompress.hip"]
 CXX_SOURCES = ["frame.cpp", "host_staging.cpp"]
 HEADERS = ["kernels.h", "lzf_device.h", "lz4_decompress_batch_phase.inc", "lz4_decompress_parse_phase.inc",
-           "analysis/lz4_decompress_copy3.inc", "analysis/capi_analysis.inc",
-           "analysis/lz4_decompress_gwalk_phase.inc", "lzf_copy_helpers.h", "lzf_parse_helpers.h", "lzf_compress_common.h", "lzf_simt.h", "analysis/lz4_compress_rows.inc", "lz4_compress_team.inc",
+           "analysis/capi_analysis.inc",
+           "lzf_copy_helpers.h", "lzf_parse_helpers.h", "lzf_compress_common.h", "lzf_simt.h", "lz4_compress_team.inc",
            "host_staging.h",
            os.path.join(ROOT, "include", "lzfear_hip.h"), os.path.join(ROOT, "include", "lzfear_frame.h")]
 
@@ -49,8 +49,11 @@ def _newest_header():
     return max((os.path.getmtime(_path(h)) for h in HEADERS if os.path.exists(_path(h))), default=0.0)
 
 
+LAST_BUILD = {}      # out path -> "compiled N of M sources + linked" | "reused (newer than its sources)": what build_library did last
+
+
 def build_library(force=False, verbose=False, defines=(), out=None, analysis=False):
-    """hipcc --offload-arch=gfx950 -> rust-lz-fear_amd/liblzfear_hip.so (or `out`)."""
+    """hipcc --offload-arch=gfx950 -> rust-lz-fear_amd/liblzfear_hip.so (or `out`).  LAST_BUILD[out] says whether hipcc ran."""
     defines = list(defines)
     if (analysis or any(d.startswith("LZF_DBG") for d in defines)) and "LZF_ANALYSIS" not in defines:
         defines.append("LZF_ANALYSIS")
@@ -61,6 +64,9 @@ def build_library(force=False, verbose=False, defines=(), out=None, analysis=Fal
     out = out or (ANALYSIS_LIB_PATH if analysis else LIB_PATH)
     srcs_t = max([os.path.getmtime(_path(s)) for s in _sources(analysis)] + [_newest_header()])
     if not force and os.path.exists(out) and os.path.getmtime(out) >= srcs_t:
+        LAST_BUILD[out] = "reused (the library is newer than every source and header)"
+        if verbose:
+            print(f"[build] {os.path.basename(out)}: {LAST_BUILD[out]}", flush=True)
         return out                                  # (also the GPU box's case: the built library travels, the objects do not)
     tag = "product" if not defines else hashlib.sha1(" ".join(sorted(defines)).encode()).hexdigest()[:12]
     objdir = os.path.join(PKG_DIR, "_obj", tag)
@@ -90,6 +96,9 @@ def build_library(force=False, verbose=False, defines=(), out=None, analysis=Fal
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    LAST_BUILD[out] = f"compiled {len(todo)} of {len(jobs)} sources with hipcc --offload-arch=gfx950, linked"
+    if verbose:
+        print(f"[build] {os.path.basename(out)}: {LAST_BUILD[out]}", flush=True)
     return out
 
 

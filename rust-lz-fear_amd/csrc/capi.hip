@@ -48,7 +48,8 @@ int ensure_device() {
 }
 
 // The geometry every dispatch threshold below is derived from: compute units and LDS bytes per CU of the current device, as the
-// runtime reports them (MI355X: 256 and 160 KiB).  Nothing in this file assumes those two numbers.
+// runtime reports them (MI355X: 256 and 160 KiB).  The thresholds are functions of those two numbers (the segmented pipeline's
+// batch limit additionally of its rank kernels' 1024-job workgroup, kSegRankMax).
 struct Geometry { uint32_t cu, lds; };
 const Geometry& geometry() {
     static const Geometry g = [] {
@@ -57,8 +58,7 @@ const Geometry& geometry() {
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) {
             r.cu = (uint32_t)p.multiProcessorCount;
             if (p.maxSharedMemoryPerMultiProcessor >= 64u * 1024u) r.lds = (uint32_t)p.maxSharedMemoryPerMultiProcessor;
-        }
-        (void)hipGetLastError();
+        } else (void)hipGetLastError();      // (only an error of these two calls is cleared, never one the caller left pending)
 #ifdef LZF_ANALYSIS      // LZF_FAKE_CU=n: dispatch as if the device had n compute units (test of the derived thresholds on one device)
         if (const char* e = getenv("LZF_FAKE_CU")) { const long v = atol(e); if (v >= 1 && v <= 4096) r.cu = (uint32_t)v; }
 #endif
@@ -114,7 +114,9 @@ constexpr uint32_t kSegMinIn = 64u * 1024u;                          // smaller 
 // for the pair kernel) and gives a block the largest ring that still leaves every block of the batch resident at once.
 constexpr uint32_t kSegRingSlack = 8u * 1024u;
 inline uint32_t seg_blocks_per_cu(uint32_t ring) { return per_cu(ring + kSegRingSlack); }
-inline uint32_t seg_max_jobs() { return seg_blocks_per_cu(32768u) * cu_count(); }
+// (capped by lzf_seg_by_len_kernel / lzf_seg_order_kernel: one 1024-thread workgroup ranks the batch in a `cost[1024]` LDS array, lz4_decompress_seg.hip)
+constexpr uint32_t kSegRankMax = 1024u;
+inline uint32_t seg_max_jobs() { const uint32_t n = seg_blocks_per_cu(32768u) * cu_count(); return n < kSegRankMax ? n : kSegRankMax; }
 inline uint32_t seg_ring_for(uint32_t n) {
     return n <= seg_blocks_per_cu(131072u) * cu_count() && geometry().lds >= 131072u + kSegRingSlack ? 131072u
          : n <= seg_blocks_per_cu(65536u) * cu_count() && geometry().lds >= 65536u + kSegRingSlack ? 65536u : 32768u;
@@ -252,17 +254,16 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
     // others to the general kernel; which is which is in the job array, i.e. in HBM, so both are launched (a wave of the
     // kernel that does not own a job reads the job and returns) unless the caller vouches for the batch with
     // LZF_KINDS_U32_FRESH_ONLY.
-    uint32_t use_compact = 1u, use_order = 1u, use_rows = 0u;
+    uint32_t use_compact = 1u, use_order = 1u;
     // The latency class: a call with no more jobs than the chip has compute units gives every compact-table job a CU of its own —
     // lzf_compress_team_kernel, three wavefronts per block, input window and table in LDS (lz4_compress_team.inc) — instead of a lone
     // wavefront of the compact kernel.  (Needs a CU's whole LDS; LZF_COMPRESS_TEAM_MAX in the analysis flavour moves the threshold.)
     uint32_t team_max = geometry().lds >= kTeamLds ? kTeamRounds * cu_count() : 0u;
 #ifdef LZF_ANALYSIS
-    // LZF_COMPRESS_KERNEL = general (everything on lzf_compress_wave_kernel) | rows (round 4's four-blocks-per-wavefront kernel,
-    // analysis/lz4_compress_rows.hip: measured slower than the compact kernel at every batch size, kept as a variant; profiles/r04_compress_rows.txt)
-    { static const uint32_t which = [] { const char* e = getenv("LZF_COMPRESS_KERNEL"); return !e ? 0u : !strcmp(e, "general") ? 1u : !strcmp(e, "rows") ? 2u : 0u; }();
+    // LZF_COMPRESS_KERNEL = general (everything on lzf_compress_wave_kernel) | compact (no latency class)
+    { static const uint32_t which = [] { const char* e = getenv("LZF_COMPRESS_KERNEL"); return !e ? 0u : !strcmp(e, "general") ? 1u : !strcmp(e, "compact") ? 3u : 0u; }();
       static const uint32_t order = analysis_order("LZF_COMPRESS_ORDER");
-      use_compact = which == 1u ? 0u : 1u; use_rows = which == 2u ? 1u : 0u; use_order = order;
+      use_compact = which == 1u ? 0u : 1u; use_order = order;
       static const long tm = [] { const char* e = getenv("LZF_COMPRESS_TEAM_MAX"); return e ? atol(e) : -1L; }();
       if (tm >= 0 && geometry().lds >= kTeamLds) team_max = (uint32_t)tm;
       if (which != 0u) team_max = 0u; }
@@ -273,16 +274,16 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
     AsyncScratch scratch_owner; scratch_owner.st = st;
     void*& scratch = scratch_owner.p;
     // the cost of a compress job is not known from its size: probe (aux_kernels.hip), then longest first
-    const bool want_order = use_order && use_compact && (table_kinds & LZF_KINDS_U32) && (use_order == 2u || n_jobs > per_cu(8704u) * cu_count());      // (more jobs than compact-kernel waves the chip holds: 18 per CU)
+    const bool want_order = use_order && use_compact && (table_kinds & LZF_KINDS_U32) && (use_order == 2u || n_jobs > per_cu(lzf::kCompactLdsBytes) * cu_count());      // (more jobs than compact-kernel waves the chip holds: 18 per CU by LDS)
     uint32_t piece = 65536u, parts = 1u;            // one 64 KiB piece from the middle of each payload (more or smaller pieces order no better)
 #ifdef LZF_ANALYSIS      // LZF_PROBE="piece,parts": the cost probe's sample (A/B of the launch order's estimate)
     { static const char* e = getenv("LZF_PROBE"); if (e) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 4096u && b >= 1u && b <= 16u) { piece = a; parts = b; } } }
 #endif
     const size_t n_probes = want_order ? (size_t)n_jobs * parts : 0u;
-    const size_t probes_off = 256;                  // [queue of the rows variant][probe jobs][probe results][perm]
+    const size_t probes_off = 256;                  // [probe jobs][probe results][perm]
     const size_t res_off = probes_off + align_up(sizeof(lzf_compress_job) * n_probes, 256);
     const size_t perm_off = res_off + align_up(sizeof(lzf_job_result) * n_probes, 256);
-    if (want_order || use_rows) {
+    if (want_order) {
         // (the order is an optimisation: without scratch memory the batch simply runs in the caller's order)
         if (hipMallocAsync(&scratch, perm_off + sizeof(uint32_t) * (want_order ? (size_t)n_jobs : 0u), st) != hipSuccess) { (void)hipGetLastError(); scratch = nullptr; }
     }
@@ -298,30 +299,15 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
 #ifdef LZF_DBG_DRY_MAIN      // analysis: results[].reserved = probe batches + sequences of the whole job (no output)
         if (use_compact) LAUNCH(k_compact_dry, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, 0u);
 #else
-        bool rows_done = false;
-#ifdef LZF_ANALYSIS
-        if (use_compact && use_rows && scratch) {
-            // four jobs per wavefront on persistent waves, 4 waves per CU; each row of a wave takes jobs from a queue until it is
-            // empty; a batch that does not fill the rows of the chip spreads over more waves
-            uint32_t* queue = reinterpret_cast<uint32_t*>(scratch);
-            HIP_TRY(hipMemsetAsync(queue, 0, 256, st));
-            const uint32_t rows_waves = 4u * cu_count();
-            uint32_t rows_active = (n_jobs + rows_waves - 1u) / rows_waves;
-            if (rows_active > 4u) rows_active = 4u;
-            const uint32_t need = (n_jobs + rows_active - 1u) / rows_active;
-            LAUNCH(lzf::lzf_compress_rows_kernel, dim3(need < rows_waves ? need : rows_waves), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, queue, rows_active, fresh_only ? 1u : 0u);
-            rows_done = true;
-        }
-#endif
-        if (use_team && !rows_done) LAUNCH(lzf::lzf_compress_team_kernel, dim3(n_jobs), dim3(192), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, fresh_only ? 1u : 0u);
-        else if (use_compact && !rows_done) LAUNCH(k_compact, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, fresh_only ? 1u : 0u);
+        if (use_team) LAUNCH(lzf::lzf_compress_team_kernel, dim3(n_jobs), dim3(192), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, fresh_only ? 1u : 0u);
+        else if (use_compact) LAUNCH(k_compact, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, fresh_only ? 1u : 0u);
 #endif
         if (!fresh_only) LAUNCH(k_general_u32, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, use_compact, (const uint32_t*)perm);
     }
     if (table_kinds & LZF_KINDS_U16)
         LAUNCH(k_general_u16, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, 0u, (const uint32_t*)perm);
     g_last_compress = !(table_kinds & LZF_KINDS_U32) ? "lzf_compress_wave_kernel<U16>"
-                    : !use_compact ? "lzf_compress_wave_kernel (analysis: general)" : use_rows ? "lzf_compress_rows_kernel (analysis)"
+                    : !use_compact ? "lzf_compress_wave_kernel (analysis: general)"
                     : use_team ? (fresh_only ? "lzf_compress_team_kernel" : "lzf_compress_team_kernel + lzf_compress_wave_kernel")
                                : (fresh_only ? "lzf_compress_compact_kernel" : "lzf_compress_compact_kernel + lzf_compress_wave_kernel");
     HIP_TRY(scratch_owner.release());

@@ -72,14 +72,16 @@ struct Staging::Pool {
         std::unique_lock<std::mutex> g(m);
         cv_done.wait(g, [this] { return pending == 0; });
     }
-    // wait for a condition a task establishes; the calling thread runs queued tasks meanwhile (with no worker threads at all —
-    // lzf_frame_set_host_threads(LZF_HOST_THREADS_NONE) — it runs every one of them, in order)
+    // wait for a condition a task establishes.  With no worker threads at all — lzf_frame_set_host_threads(LZF_HOST_THREADS_NONE) — the
+    // calling thread runs the queued tasks itself, in order; with workers it only waits: it is the thread that issues the DMA of a
+    // finished piece, and inside a 4 MiB memcpy of its own it would issue that DMA late (the staging would serialise with the link)
     template <class Pred> void wait_until(Pred p) {
         for (;;) {
             std::function<void()> f;
             {
                 std::unique_lock<std::mutex> g(m);
                 if (p()) return;
+                if (!th.empty()) { cv_done.wait(g, [&] { return p(); }); return; }
                 if (q.empty()) { cv_done.wait(g, [&] { return p() || !q.empty(); }); if (p()) return; }
                 if (!q.empty()) { f = std::move(q.front()); q.pop_front(); }
             }

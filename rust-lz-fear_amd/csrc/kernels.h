@@ -2,8 +2,9 @@
 //
 // The product library (build.py, no defines) holds the kernels lzf_decompress_batch / lzf_compress_batch launch:
 // paired48, paired24, staged16, the two compress kernels and the small helpers.  -DLZF_ANALYSIS (liblzfear_hip_analysis.so)
-// adds every other kernel generation — kept for A/B timing and counter studies (tools/, profiles/) — and the environment
-// variables that select them; nothing below an `#ifdef LZF_ANALYSIS` is in the product.
+// adds the first-generation kernel and the tuning variants of the batched / paired kernels — kept for A/B timing and counter
+// studies (tools/, profiles/) — and the environment variables that select them (the windowed, v6 and row-mapped generations of
+// rounds 2-4 left the tree in round 5: git tag r4-kernel-generations); nothing below an `#ifdef LZF_ANALYSIS` is in the product.
 #pragma once
 #include "lzf_device.h"
 
@@ -29,20 +30,6 @@ __global__ __launch_bounds__(64) void lzf_decompress_batched_kernel(const lzf_de
 #define LZF_EXT(NAME, R, S_, T, ST) extern template __global__ void lzf_decompress_batched_kernel<R, S_, T, ST>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*);
 LZF_DECOMPRESS_VARIANTS(LZF_EXT)
 #undef LZF_EXT
-#ifdef LZF_ANALYSIS
-// Third generation (lz4_decompress_windowed.hip): X(name, ring bytes, region bytes).  The token list of a chunk lives
-// in a scratch area of LZF_WINDOWED_STRIDE(region) u16 entries per job.
-template <int RING, int R, int WIN>
-__global__ void lzf_decompress_windowed_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results,
-                                               uint32_t n_jobs, uint16_t* __restrict__ scratch, uint32_t scratch_stride);
-#define LZF_WINDOWED_STRIDE(R_) ((((64u * (R_)) / 3u + 1u + 64u) + 63u) & ~63u)
-#define LZF_WINDOWED_VARIANTS(X) \
-    X(win512, 4096, 512, 64)   \
-    X(win1024, 4096, 1024, 64)
-#define LZF_EXTW(NAME, RG, R_, W_) extern template __global__ void lzf_decompress_windowed_kernel<RG, R_, W_>(const lzf_decompress_job*, lzf_job_result*, uint32_t, uint16_t*, uint32_t);
-LZF_WINDOWED_VARIANTS(LZF_EXTW)
-#undef LZF_EXTW
-#endif
 // Producer / consumer pairs (lz4_decompress_paired.hip): X(name, ring bytes, region bytes, token-list entries).
 // (The launch bounds are repeated on the template DECLARATIONS of this header since round 4: hipcc takes a template kernel's
 //  attributes from its first declaration, and without them the instantiations were compiled for 1 024-thread workgroups.)
@@ -66,29 +53,6 @@ __global__ __launch_bounds__(128) void lzf_decompress_paired_kernel(const lzf_de
 #define LZF_EXTP(NAME, RG, S_, T) extern template __global__ void lzf_decompress_paired_kernel<RG, S_, T>(const lzf_decompress_job*, lzf_job_result*, uint32_t, const uint32_t*, const seg_job*);
 LZF_PAIRED_VARIANTS(LZF_EXTP)
 #undef LZF_EXTP
-#ifdef LZF_ANALYSIS
-// Sixth generation (lz4_decompress_v6.hip): parse and copy as two launches; X(name, window bytes, region bytes).
-__global__ void lzf_v6_plan_kernel(const lzf_decompress_job* __restrict__ jobs, uint32_t n_jobs, uint32_t base, uint32_t stride, uint32_t cnt, const uint32_t* __restrict__ perm,
-                                   uint32_t chunk_bytes, uint64_t* __restrict__ tok_off, uint64_t* __restrict__ tab_off);
-template <int S, bool STAGED>
-__global__ void lzf_v6_parse_kernel(const lzf_decompress_job* __restrict__ jobs, uint32_t n_jobs, uint32_t base, uint32_t stride, const uint32_t* __restrict__ perm,
-                                    const uint64_t* __restrict__ tok_off, const uint64_t* __restrict__ tab_off, uint32_t* __restrict__ toks_all, uint32_t* __restrict__ tabs_all);
-template <int W>
-__global__ void lzf_v6_copy_kernel(const lzf_decompress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs, uint32_t base, uint32_t stride,
-                                   const uint32_t* __restrict__ perm, const uint64_t* __restrict__ tok_off, const uint64_t* __restrict__ tab_off,
-                                   const uint32_t* __restrict__ toks_all, const uint32_t* __restrict__ tabs_all);
-#define LZF_V6_VARIANTS(X) \
-    X(v6s512, 4096, 512, false)  \
-    X(v6l256, 4096, 256, true)   \
-    X(v6l128, 4096, 128, true)   \
-    X(v6l384, 4096, 384, true)   \
-    X(v6l256w6, 6144, 256, true)
-#define LZF_EXT6(NAME, W_, S_, ST) \
-    extern template __global__ void lzf_v6_parse_kernel<S_, ST>(const lzf_decompress_job*, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint64_t*, const uint64_t*, uint32_t*, uint32_t*); \
-    extern template __global__ void lzf_v6_copy_kernel<W_>(const lzf_decompress_job*, lzf_job_result*, uint32_t, uint32_t, uint32_t, const uint32_t*, const uint64_t*, const uint64_t*, const uint32_t*, const uint32_t*);
-LZF_V6_VARIANTS(LZF_EXT6)
-#undef LZF_EXT6
-#endif  // LZF_ANALYSIS
 // ---------------------------------------------------------------------------------------------------------------------
 // Segmented decompress (lz4_decompress_seg.hip): one block decoded by MANY wavefronts, as a pipeline of launches over the
 // whole batch.  Used for batches that leave the chip mostly empty with one workgroup per block (per-block latency regime).
@@ -160,6 +124,8 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(const lzf_compres
                                          const uint32_t* __restrict__ perm);
 extern template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U32>(const lzf_compress_job*, lzf_job_result*, uint32_t, uint32_t, const uint32_t*);
 extern template __global__ void lzf_compress_wave_kernel<LZF_TABLE_U16>(const lzf_compress_job*, lzf_job_result*, uint32_t, uint32_t, const uint32_t*);
+// LDS of one workgroup of lzf_compress_compact_kernel: 2048 words of slots + 128 of epoch parities + one scratch word per lane (the dispatch derives its residency from this)
+constexpr uint32_t kCompactLdsBytes = (4096u / 2u + 4096u / 32u + 64u) * 4u;
 template <bool DRY>
 __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(const lzf_compress_job* __restrict__ jobs,
                                             lzf_job_result* __restrict__ results, uint32_t n_jobs, const uint32_t* __restrict__ perm,
@@ -169,12 +135,6 @@ extern template __global__ void lzf_compress_compact_kernel<true>(const lzf_comp
 // the latency class (lz4_compress_team.hip / .inc; round 5): one block per CU, searcher / emitter / feeder wavefronts, input ring and table in LDS
 __global__ void lzf_compress_team_kernel(const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
                                          const uint32_t* __restrict__ perm, uint32_t alone);
-#ifdef LZF_ANALYSIS
-// four blocks per wavefront, persistent waves (analysis/lz4_compress_rows.hip / .inc; round 4, analysis variant): the compact-table jobs of a
-// batch; queue = next position of perm[] (or of the job array) to hand out, zero before the launch; rows_active = rows of a wave that take jobs
-__global__ void lzf_compress_rows_kernel(const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
-                                         const uint32_t* __restrict__ perm, uint32_t* __restrict__ queue, uint32_t rows_active, uint32_t alone);
-#endif
 // job ordering (aux_kernels.hip): cost probes of the compress jobs and the launch order derived from them
 __global__ void lzf_cost_probe_jobs_kernel(const lzf_compress_job* __restrict__ jobs, lzf_compress_job* __restrict__ probes, uint32_t n,
                                            uint32_t piece, uint32_t parts);

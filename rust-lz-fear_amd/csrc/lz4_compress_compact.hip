@@ -50,6 +50,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
     __shared__ __attribute__((aligned(16))) uint32_t tab32[kSlots / 2 + kSlots / 32 + kWave + LZF_DBG_LDS_PAD / 4];      // occupancy experiment
 #else
     __shared__ __attribute__((aligned(16))) uint32_t tab32[kSlots / 2 + kSlots / 32 + kWave];
+    static_assert(sizeof(tab32) == kCompactLdsBytes, "capi.hip derives the kernel's residency from kCompactLdsBytes");
 #endif
     uint32_t* const par = tab32 + kParBase;
     uint16_t* const tab16 = reinterpret_cast<uint16_t*>(tab32);
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     // bytes (:211: cursor - literal_start), so only input[ls .. ls + k) matters — and that is in the lanes' registers:
                     // lane k >= 8 takes lane k - 8's probe bytes, lane k < 8 the run's first k bytes in the top of the word (the rest
                     // is never looked at: the bound cuts it off).  One load fewer per sequence; worked out behind the gather's issue.
+                    static_assert(kFirstBatch <= 16u, "pa_regs: row_shr:8 stays inside a DPP row of 16 lanes — a wider first batch needs a cross-row fetch");
                     const bool pa_regs = n == 0u;
                     if (reach) {
                         B0 = ld8(in + cand); B1 = ld8(in + cand + 8u);

@@ -1,5 +1,5 @@
 """Parity check of whatever compress kernel LZF_COMPRESS_KERNEL selects ("general" keeps fresh-table U32 jobs on
-lzf_compress_wave_kernel; default = lzf_compress_compact_kernel).  Run as a script by
+lzf_compress_wave_kernel, "compact" switches the latency class off; default for a batch of this size = lzf_compress_team_kernel).  Run as a script by
 tests/test_gpu_parity.py::test_every_compress_kernel (the choice is read once per process, hence the subprocess)."""
 import os
 import sys
@@ -24,6 +24,9 @@ def main():
     cases += [("mix700k", big), ("zeros_noise_zeros", zeros + noise + zeros + big[:70_000] + zeros[:140_000] + big[:70_000]),
               ("noise_then_repeat", noise + noise[:150_000] + big[:100_000])]
     res = ffi.compress_blocks_host([dict(input=d, out_cap=len(d) + len(d) // 200 + 64) for _, d in cases])
+    launch = ffi.lib().lzf_last_compress_launch().decode()
+    want = {"general": "lzf_compress_wave_kernel", "compact": "lzf_compress_compact_kernel"}.get(os.environ.get("LZF_COMPRESS_KERNEL", ""), "lzf_compress_team_kernel")
+    assert launch.startswith(want), (launch, want)
     for (name, d), (rc, out) in zip(cases, res):
         erc, eout = o.compress2(d)
         assert rc == erc and out == eout, name

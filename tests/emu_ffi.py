@@ -1,8 +1,8 @@
-"""ctypes binding of tests/emu/libemu_compress_rows.so and libemu_compress_team.so — TEST INFRASTRUCTURE ONLY.
+"""ctypes binding of tests/emu/libemu_compress_team.so — TEST INFRASTRUCTURE ONLY.
 
-The libraries are the sources of two compress kernels — the row-mapped one (rust-lz-fear_amd/csrc/analysis/lz4_compress_rows.inc) and the
-team kernel of the latency class (rust-lz-fear_amd/csrc/lz4_compress_team.inc: searcher / emitter / feeder wavefronts per block) —
-compiled with g++ against the lock-step wavefront emulator of lzf_simt.h; see tests/emu/emu_compress_*.cpp.  The product never loads them.
+The library is the source of the team compress kernel of the latency class (rust-lz-fear_amd/csrc/lz4_compress_team.inc: searcher /
+emitter / feeder wavefronts per block) compiled with g++ against the lock-step wavefront emulator of lzf_simt.h; see
+tests/emu/emu_compress_team.cpp.  The product never loads it.
 """
 import ctypes as C
 import os
@@ -23,7 +23,6 @@ class JobResult(C.Structure):
     _fields_ = [("out_len", C.c_uint64), ("status", C.c_int32), ("reserved", C.c_uint32)]
 
 
-_lib = None
 _team = None
 
 
@@ -47,28 +46,8 @@ def team_lib():
     return _team
 
 
-def build(force=False):
-    so = os.path.join(EMU_DIR, "libemu_compress_rows.so")
-    deps = [os.path.join(EMU_DIR, "emu_compress_rows.cpp")] + [os.path.join(CSRC, f) for f in
-            ("analysis/lz4_compress_rows.inc", "lzf_simt.h", "lzf_compress_common.h")] + [os.path.join(INCLUDE, "lzfear_hip.h")]
-    if force or not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra", "-o", so, deps[0]])
-    return so
-
-
-def lib():
-    global _lib
-    if _lib is None:
-        L = C.CDLL(build())
-        L.lzf_emu_compress_rows.restype = C.c_int
-        L.lzf_emu_compress_rows.argtypes = [C.POINTER(CompressJob), C.POINTER(JobResult), C.c_uint32, C.POINTER(C.c_uint32),
-                                            C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
-        _lib = L
-    return _lib
-
-
-def compress_batch(inputs, cursors=None, caps=None, tables=None, n_waves=1, rows_active=4, perm=None, pad=64, kernel="rows"):
-    """Runs the emulated kernel ("rows" or "team") over a batch.  inputs: list of bytes.  Returns [(status, bytes)], lock-step points per wave sum."""
+def compress_batch(inputs, cursors=None, caps=None, tables=None, perm=None, pad=64, kernel="team"):
+    """Runs the emulated team kernel over a batch.  inputs: list of bytes.  Returns [(status, bytes)], lock-step points per wave sum."""
     n = len(inputs)
     jobs = (CompressJob * n)()
     res = (JobResult * n)()
@@ -96,10 +75,8 @@ def compress_batch(inputs, cursors=None, caps=None, tables=None, n_waves=1, rows
     if perm is not None:
         permarr = (C.c_uint32 * n)(*perm)
     ns = C.c_uint64(0)
-    if kernel == "team":
-        rc = team_lib().lzf_emu_compress_team(jobs, res, n, permarr, 1, C.byref(ns))
-    else:
-        rc = lib().lzf_emu_compress_rows(jobs, res, n, permarr, n_waves, rows_active, 1, C.byref(ns))
+    assert kernel == "team"
+    rc = team_lib().lzf_emu_compress_team(jobs, res, n, permarr, 1, C.byref(ns))
     assert rc == 0, rc
     result = []
     for i in range(n):

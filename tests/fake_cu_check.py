@@ -22,7 +22,10 @@ def main():
     bigc = [o.compress2(d)[1] for d in big]
     assert all(len(c) >= 65536 for c in bigc)
     seen = {}
-    for n in (cu - 4, cu + 4, 2 * cu + 4, 4 * cu - 4, 4 * cu + 8, 8 * cu + 8, 64 * cu + 16):
+    # more compute units than the pipeline's rank kernels take jobs (one 1024-thread workgroup, capi.hip kSegRankMax): with
+    # LZF_FAKE_CU=512 the pipeline's limit is 1024 jobs, not 4 x 512 — 1000 jobs go through it, 1500 go to the pair kernel
+    sizes = (1000, 1500) if cu > 256 else (cu - 4, cu + 4, 2 * cu + 4, 4 * cu - 4, 4 * cu + 8, 8 * cu + 8, 64 * cu + 16)
+    for n in sizes:
         raws, comps = [], []
         for i in range(n):
             if i % 16 == 0:
@@ -36,6 +39,11 @@ def main():
             assert rc == 0 and out == d, (n, i, rc)
         seen[n] = launch
         print(n, launch, flush=True)
+    if cu > 256:
+        assert seen[1000].startswith("segmented"), seen[1000]
+        assert not seen[1500].startswith("segmented") and "lzf_decompress_paired_kernel<4096,48,640>" in seen[1500], seen[1500]
+        print("geometry ok")
+        return
     want = {cu - 4: "resolve_pair_kernel<131072>", cu + 4: "resolve_pair_kernel<65536>", 2 * cu + 4: "resolve_pair_kernel<32768>", 4 * cu - 4: "resolve_pair_kernel<32768>",
             4 * cu + 8: "lzf_decompress_paired_kernel<4096,48,640>", 8 * cu + 8: "lzf_decompress_paired_kernel<4096,24,384>", 64 * cu + 16: "staged"}
     for n, frag in want.items():

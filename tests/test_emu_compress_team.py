@@ -19,7 +19,6 @@ from rust_lz_fear_amd import synth
 
 
 def run(inputs, cursors=None, caps=None, tables=None, **kw):
-    kw.pop("rows_active", None); kw.pop("n_waves", None)
     res, _ = emu_ffi.compress_batch(inputs, cursors=cursors, caps=caps, tables=tables, kernel="team", **kw)
     return res
 
@@ -61,7 +60,7 @@ def test_medium_corpus_pieces(part):
     cases = vectors.medium_cases()
     cases = [(n, d[: 320 << 10]) for n, d in cases][part::3]      # the 128 KiB ring wraps twice; candidates up to 64 KiB back
     inputs = [d for _, d in cases]
-    expect(inputs, run(inputs, n_waves=2), names=[n for n, _ in cases])
+    expect(inputs, run(inputs), names=[n for n, _ in cases])
 
 
 def test_incompressible_and_skip_schedule():
@@ -145,7 +144,7 @@ def test_random_structures():
                 for _ in range(ln): buf.append(buf[-dist])
             else: buf += synth.gen_text_zipf(rng.randrange(1000), rng.randrange(1, 500)).tobytes()
         inputs.append(bytes(buf[:n]))
-    expect(inputs, run(inputs, n_waves=2))
+    expect(inputs, run(inputs))
 
 
 def test_ring_skips_and_far_candidates():

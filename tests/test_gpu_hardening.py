@@ -115,3 +115,8 @@ def test_dispatch_thresholds_follow_the_device_geometry():
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "geometry ok" in r.stdout
+    # ... and with MORE compute units than the pipeline's rank kernels take jobs (round-4 advisor finding): the limit stays 1024
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "fake_cu_check.py")], env=_analysis_env(LZF_FAKE_CU="512"),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "geometry ok" in r.stdout

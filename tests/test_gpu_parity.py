@@ -165,8 +165,7 @@ def _analysis_env(**kw):
     return dict(os.environ, LZF_LIB_PATH=path, **kw)
 
 
-@pytest.mark.parametrize("variant", ["auto", "wave", "staged16", "staged32", "direct4w", "win512", "win1024", "paired16", "paired24", "paired48", "paired256",
-                                     "v6l256", "seg", "ordered"])
+@pytest.mark.parametrize("variant", ["auto", "wave", "staged16", "staged32", "direct4w", "paired16", "paired24", "paired48", "paired256", "seg", "ordered"])
 def test_every_decompress_kernel_generation(variant):
     """Every kernel generation kept in the analysis library (and every ring/region geometry) implements the same contract.
     "ordered": the longest-first launch order that large batches get, forced on for these small ones.
@@ -180,12 +179,12 @@ def test_every_decompress_kernel_generation(variant):
     assert "variant ok" in r.stdout
 
 
-@pytest.mark.parametrize("kernel", ["rows", "compact", "general", "ordered"])
+@pytest.mark.parametrize("kernel", ["team", "compact", "general", "ordered"])
 def test_every_compress_kernel(kernel):
-    """Fresh-table U32 jobs through the compact-table kernel (default), the general kernel and round 4's row-mapped variant
-    (four blocks per wavefront, persistent waves, a job queue — the same source the CPU suite runs under the lock-step
-    emulator, tests/test_emu_compress_rows.py): same bytes as the oracle, over inputs that cross several 64 KiB epochs,
-    skip epochs inside one match and widen the batches.
+    """Fresh-table U32 jobs through the team kernel of the latency class (the default for a batch this small: three wavefronts per
+    block, input ring and table in LDS — the same source the CPU suite runs under the lock-step emulator,
+    tests/test_emu_compress_team.py), the compact-table kernel (the default beyond one block per CU) and the general kernel: same
+    bytes as the oracle, over inputs that cross several 64 KiB epochs / ring wraps, skip epochs inside one match and widen the batches.
     "ordered": the cost probe + longest-first queue order that large batches get, forced on for this small one."""
     import subprocess, sys
     env = _analysis_env(LZF_COMPRESS_KERNEL=kernel) if kernel != "ordered" else _analysis_env(LZF_COMPRESS_ORDER="always")
