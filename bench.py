@@ -226,7 +226,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["silesia", "config4"], default="silesia")
+    ap.add_argument("--workload", choices=["silesia", "config4", "config5"], default="silesia")
     ap.add_argument("--copies", type=int, default=240, help="silesia: tiled copies of silesia_mix per GPU (51 blocks each)")
     ap.add_argument("--distinct", type=int, default=12, help="silesia: copies generated with their own seeds (the rest are rotated + XOR-ed)")
     ap.add_argument("--blocks", type=int, default=2048, help="config4: 4 MiB blocks of the whole stream (2048 = 8 GiB)")
@@ -235,6 +235,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-config4", action="store_true", help="silesia workload: skip the strong-scaled configs[3] leg of the line")
+    ap.add_argument("--no-config5", action="store_true", help="silesia workload: skip the configs[4] leg of the line (linked 64 KiB blocks + dictionary, U16Table)")
+    ap.add_argument("--streams", type=int, default=4096, help="config5: linked-block streams of 1 MiB per GPU")
     ap.add_argument("--launch-check", action="store_true",
                     help="no GPU work: every rank joins a gloo group, the ranks agree on their block ranges, rank 0 prints them (test of the self-launch path)")
     args = ap.parse_args()
@@ -270,6 +272,8 @@ def main():
 
     if args.workload == "config4":
         line = run_config4(args, torch, device, ffi, dist, rank, world, dev)
+    elif args.workload == "config5":
+        line = run_config5(args, torch, device, ffi, dist, rank, world, dev)
     else:
         line = run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases)
         if not args.no_config4:
@@ -286,6 +290,14 @@ def main():
                                    "n_ranks_seen_by_rccl": l4["config"]["n_ranks_seen_by_rccl"], "blocks": l4["config"]["blocks"],
                                    "verified_against_oracle_prefix": l4["config"]["verified_against_oracle_prefix"],
                                    "content_checksum": l4["config"]["content_checksum"]}
+        if not args.no_config5 and world == 1:
+            # configs[4]: linked 64 KiB blocks behind a dictionary (many streams in lock-step) and raw U16Table jobs, device-resident
+            import copy, gc
+            gc.collect(); torch.cuda.empty_cache()
+            a5 = copy.copy(args); a5.steps = max(1, min(args.steps, 3)); a5.warmup = 1
+            l5 = run_config5(a5, torch, device, ffi, dist, rank, world, dev)
+            if rank == 0:
+                line["config5"] = {k: l5[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "roofline", "compress", "u16_raw")}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist:
@@ -341,6 +353,7 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
     torch.cuda.synchronize()
     tc0 = time.perf_counter()
     c_evs = timed_launches(torch, compress_step, c_steps)
+    c_launch = ffi.lib().lzf_last_compress_launch().decode()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -501,7 +514,7 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
                      "issue_ceiling": issue_ceiling(copies, d_kernel_ms, d_achieved)},
         "compress": {"value": round(total_bytes * c_steps / tc_max / 2**30, 3), "unit": "GiB/s (uncompressed bytes compressed per second)",
                      "steps": c_steps, "ms_per_step": round(tc_max / c_steps * 1e3, 3),
-                     "roofline": {"bound": "hbm", "kernel": "lzf_compress_compact_kernel<false>",
+                     "roofline": {"bound": "hbm", "kernel": c_launch,
                                   "achieved": round(c_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(c_achieved / HBM_PEAK_GBS, 5), "traffic": c_traffic, "traffic_provenance": c_traffic_info,
                                   "algorithmic_bytes_per_launch": c_bytes, "kernel_ms": round(c_kernel_ms, 3)}},
@@ -607,6 +620,7 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
         a, b, c2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         device.compress_batch(d_cj, d_cres, nloc, ffi.KINDS_U32 | ffi.KINDS_U32_FRESH_ONLY)
+        state["launch"] = ffi.lib().lzf_last_compress_launch().decode()
         b.record()
         kev.append((a, b))
         state["frame_len"], state["comp_total"] = lzdist.gather_frame_device(d_cres, comp, src, BS, nloc, nblk_all, frame, dist, rank, world, device, header)
@@ -685,10 +699,216 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
                    "blocks": nblk_all, "block_size": BS, "parallelism": f"block ranges x{world}, all-gather over RCCL",
                    "frame_bytes": int(state["frame_len"]), "wire_bytes_in_per_rank": int(wire), "verified_against_oracle_prefix": verified,
                    "gather_ms": round(g_ms, 3), "n_ranks_seen_by_rccl": (dist.get_world_size() if dist else 0), "content_checksum": xx},
-        "roofline": {"bound": "hbm", "kernel": "lzf_compress_compact_kernel<false>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "roofline": {"bound": "hbm", "kernel": state["launch"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_for("lzf_compress_compact_kernel<false>", "compress", nloc)[0],
                      "algorithmic_bytes_per_launch": alg, "kernel_ms": round(k_ms, 4)},
         "cpu_baseline": cpu,
+    }
+
+
+# ======================================================================================= configs[4]
+def run_config5(args, torch, device, ffi, dist, rank, world, dev):
+    """BASELINE configs[4], device-resident: S streams of 1 MiB — each a 256-byte motif of its own, repeated — as frames of 64 KiB LINKED
+    blocks behind a 64 KiB dictionary of the same motif (the U32Table path, the only one the reference's frame layer has,
+    framed/compress.rs:202-214,:271-275; framed/decompress.rs:238-269): block k of every stream in launch k, the table and the window
+    carried on the device (lzf_table_offset_batch / lzf_chain_decompress_step).  Plus the raw U16Table path (mod.rs:78-101) on
+    65 535-byte slices of the same data.  Weak-scaled like the headline (every rank its own streams, no collective)."""
+    B5, SL, DL = 64 << 10, 1 << 20, 64 << 10
+    S = args.streams
+    NB = SL // B5
+    stride = DL + SL
+    t0 = time.time()
+    g = torch.Generator(device="cpu"); g.manual_seed(0x5EED0005 + rank)
+    motifs = torch.randint(0, 256, (S, 256), dtype=torch.uint8, generator=g).to(dev)
+    slab = motifs.repeat(1, stride // 256).contiguous().view(-1)               # stream s = slab[s * stride + DL : (s + 1) * stride], its dictionary in front of it
+    del motifs
+    TSZ = 4096 * 4 + 8                                                            # sizeof(lzf_u32_table)
+    d_tmpl = torch.zeros(S * TSZ, dtype=torch.uint8, device=dev)
+    d_tabs = torch.zeros(S * TSZ, dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    lib = ffi.lib()
+    torch.cuda.synchronize(); ts = time.perf_counter()
+    for s_ in range(S):                                                           # template_table (framed/compress.rs:202-211), one per dictionary
+        ffi.check(lib.lzf_table_seed_from_dictionary(d_tmpl.data_ptr() + s_ * TSZ, slab.data_ptr() + s_ * stride, DL, st))
+    torch.cuda.synchronize(); seed_ms = (time.perf_counter() - ts) * 1e3
+    comp = torch.empty(S * NB * B5, dtype=torch.uint8, device=dev)              # slot stride = block size (cap = N)
+    nj = S * NB
+    sidx = np.arange(S, dtype=np.uint64)
+    cj = np.zeros(nj, dtype=device.CJOB)
+    for k in range(NB):                                                            # step-major: jobs of step k are [k * S, (k + 1) * S)
+        v = cj[k * S:(k + 1) * S]
+        v["input"] = np.uint64(slab.data_ptr()) + sidx * np.uint64(stride) + np.uint64(k * B5)    # in_buffer = the last 64 KiB ++ block (:217-222)
+        v["input_len"] = DL + B5
+        v["cursor"] = DL
+        v["out"] = np.uint64(comp.data_ptr()) + (sidx * np.uint64(NB) + np.uint64(k)) * np.uint64(B5)
+        v["out_cap"] = B5                                                          # framed/compress.rs:242
+        v["table"] = np.uint64(d_tabs.data_ptr()) + sidx * np.uint64(TSZ)
+    cj["table_kind"] = ffi.TABLE_U32
+    d_cj = device.to_device(cj, dev)
+    d_cres = torch.zeros(nj * 16, dtype=torch.uint8, device=dev)
+    d_tabptr = torch.from_numpy((np.uint64(d_tabs.data_ptr()) + sidx * np.uint64(TSZ)).view(np.int64)).to(dev)
+    d_adds = torch.full((S,), B5, dtype=torch.int64, device=dev)                  # table.offset(forget): the window forgets 64 KiB per block (:271-275)
+    log(f"[bench] rank {rank}: config5: {S} streams x {SL >> 20} MiB ({S * SL / 2**30:.2f} GiB) + dictionaries in HBM, templates seeded in {seed_ms:.0f} ms ({time.time() - t0:.1f}s)")
+
+    def compress_step():
+        d_tabs.copy_(d_tmpl)                                                       # table = template.clone() (:213-214)
+        for k in range(NB):
+            if k:
+                ffi.check(lib.lzf_table_offset_batch(d_tabptr.data_ptr(), d_adds.data_ptr(), S, ffi.TABLE_U32, st))
+            ffi.check(lib.lzf_compress_batch(d_cj.data_ptr() + k * S * 56, d_cres.data_ptr() + k * S * 16, S, ffi.KINDS_U32, st))
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        evs = []
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); fn(); b.record(); evs.append((a, b))
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t1
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        if dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0]), float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    c_el, c_ms = timed(compress_step, args.steps, args.warmup)
+    c_launch = lib.lzf_last_compress_launch().decode()
+    cres = device.results_to_host(d_cres, nj)
+    assert np.all(cres["status"] == ffi.OK), f"config5 compress statuses: {np.unique(cres['status'])}"
+    clen = cres["out_len"].astype(np.uint64)
+
+    # ---- decompress: the stream's output is one buffer, the window is what it already holds (framed/decompress.rs:253-269)
+    dstride = SL + 2 * B5
+    dec = torch.zeros(S * dstride, dtype=torch.uint8, device=dev)
+    dj = np.zeros(nj, dtype=device.DJOB)
+    CS = np.dtype([("prev_job", "<u4"), ("job", "<u4"), ("stored_len", "<u8"), ("stored_src", "<u8"), ("out", "<u8"), ("block_maxsize", "<u8")])
+    cs = np.zeros(nj, dtype=CS)
+    for k in range(NB):
+        v = dj[k * S:(k + 1) * S]
+        v["input"] = cj["out"][k * S:(k + 1) * S]
+        v["input_len"] = clen[k * S:(k + 1) * S]
+        v["prefix"] = np.uint64(slab.data_ptr()) + sidx * np.uint64(stride)      # the dictionary (:239-245)
+        v["prefix_len"] = DL
+        v["out"] = np.uint64(dec.data_ptr()) + sidx * np.uint64(dstride)
+        v["out_cap"] = B5 + clen[k * S:(k + 1) * S]                                # (patched per step by lzf_chain_decompress_step)
+        v["output_limit"] = B5
+        c = cs[k * S:(k + 1) * S]
+        c["prev_job"] = (np.uint32(0xFFFFFFFF) if k == 0 else (np.arange(S, dtype=np.uint32) + np.uint32((k - 1) * S)))
+        c["job"] = np.arange(S, dtype=np.uint32) + np.uint32(k * S)
+        c["out"] = v["out"]
+        c["block_maxsize"] = B5
+    d_dj = device.to_device(dj, dev)
+    d_cs = device.to_device(cs, dev)
+    d_dres = torch.zeros(nj * 16, dtype=torch.uint8, device=dev)
+    d_state = torch.zeros(S * 16, dtype=torch.uint8, device=dev)
+
+    def decompress_step():
+        d_state.zero_()
+        for k in range(NB):
+            ffi.check(lib.lzf_chain_decompress_step(d_cs.data_ptr() + k * S * 40, d_state.data_ptr(), S, d_dj.data_ptr(), d_dres.data_ptr(), st))
+            ffi.check(lib.lzf_decompress_batch_sized(d_dj.data_ptr() + k * S * 64, d_dres.data_ptr() + k * S * 16, S, B5, st))
+
+    d_el, d_ms = timed(decompress_step, args.steps, args.warmup)
+    d_launch = lib.lzf_last_decompress_launch().decode()
+    dres = device.results_to_host(d_dres, nj)
+    assert np.all(dres["status"] == ffi.OK), f"config5 decompress statuses: {np.unique(dres['status'])}"
+    if not args.no_verify:
+        assert torch.equal(dec.view(S, dstride)[:, :SL], slab.view(S, stride)[:, DL:]), "config5: decoded streams differ from the source"
+    verified = None
+    if rank == 0 and not args.no_verify:
+        # the first and the last stream against the oracle's linked-block loop (framed/compress.rs:221-276), block by block
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import ctypes as C
+        import oracle_ffi as o
+        for s_ in (0, S - 1):
+            host = slab[s_ * stride:(s_ + 1) * stride].cpu().numpy().tobytes()
+            dic, data = host[:DL], host[DL:]
+            tab = o.new_table()
+            contract = C.c_int(0)
+            rep = o.lib().lzfo_u32_replace
+            rep.restype = C.c_size_t
+            rep.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_size_t, C.POINTER(C.c_int)]
+            for off in range(0, len(dic) - 7, 3):
+                rep(C.addressof(tab), dic, len(dic), off, C.byref(contract))
+            buf = dic
+            for k in range(NB):
+                blk = data[k * B5:(k + 1) * B5]
+                inp = buf + blk
+                erc, ecomp = o.compress2(inp, cursor=len(buf), table=tab, cap=len(blk))
+                q = k * S + s_
+                mine = comp[(s_ * NB + k) * B5:(s_ * NB + k) * B5 + int(clen[q])].cpu().numpy().tobytes()
+                assert erc == 0 and mine == ecomp, f"config5: stream {s_} block {k} differs from the oracle"
+                buf = inp
+                if len(buf) > 65536:
+                    forget = len(buf) - 65536
+                    tab.offset += forget
+                    buf = buf[forget:]
+        verified = True
+
+    # ---- raw U16Table jobs (mod.rs:78-101): 65 535-byte slices, fresh tables; and back
+    NU = min(4 * S, (S * stride) // 65536)
+    uj = np.zeros(NU, dtype=device.CJOB)
+    uoff = np.arange(NU, dtype=np.uint64) * np.uint64(65536)
+    uj["input"] = np.uint64(slab.data_ptr()) + uoff
+    uj["input_len"] = 65535
+    uj["out"] = np.uint64(comp.data_ptr()) + uoff
+    uj["out_cap"] = 65535
+    uj["table_kind"] = ffi.TABLE_U16
+    d_uj = device.to_device(uj, dev)
+    d_ures = torch.zeros(NU * 16, dtype=torch.uint8, device=dev)
+    u_el, u_ms = timed(lambda: ffi.check(lib.lzf_compress_batch(d_uj.data_ptr(), d_ures.data_ptr(), NU, ffi.KINDS_U16, st)), args.steps, args.warmup)
+    ures = device.results_to_host(d_ures, NU)
+    assert np.all(ures["status"] == ffi.OK)
+    ud = np.zeros(NU, dtype=device.DJOB)
+    ud["input"] = uj["out"]; ud["input_len"] = ures["out_len"]
+    ud["out"] = np.uint64(dec.data_ptr()) + uoff; ud["out_cap"] = 65535 + 64; ud["output_limit"] = 65535
+    d_ud = device.to_device(ud, dev)
+    d_udres = torch.zeros(NU * 16, dtype=torch.uint8, device=dev)
+    dec.zero_()
+    ud_el, ud_ms = timed(lambda: ffi.check(lib.lzf_decompress_batch_sized(d_ud.data_ptr(), d_udres.data_ptr(), NU, 65536, st)), args.steps, args.warmup)
+    udres = device.results_to_host(d_udres, NU)
+    assert np.all(udres["status"] == ffi.OK) and np.all(udres["out_len"] == 65535)
+    if not args.no_verify:
+        assert torch.equal(dec[: NU * 65536].view(NU, 65536)[:, :65535], slab[: NU * 65536].view(NU, 65536)[:, :65535]), "config5: U16 round trip differs"
+    if rank == 0 and not args.no_verify:
+        import oracle_ffi as o
+        h = slab[:65535].cpu().numpy().tobytes()
+        erc, ecomp = o.compress2(h, kind=o.TABLE_U16)
+        assert erc == 0 and comp[: int(ures["out_len"][0])].cpu().numpy().tobytes() == ecomp, "config5: U16Table job differs from the oracle"
+    if rank != 0:
+        return None
+    tot = float(S) * SL * world
+    N1, C1 = float(S) * SL, float(clen.sum())
+    gib = lambda bytes_, secs: round(bytes_ / secs / 2**30, 3)
+    roof = lambda alg, ms, kern: {"bound": "hbm", "kernel": kern, "achieved": round(alg / (ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": alg, "kernel_ms": round(ms, 3),
+                                  "launches_per_step": None}
+    r_d = roof(N1 + C1, d_ms, d_launch); r_d["launches_per_step"] = f"{NB} x (lzf_chain_decompress_step + lzf_decompress_batch of {S} jobs)"
+    r_c = roof(N1 + C1, c_ms, c_launch); r_c["launches_per_step"] = f"table clone + {NB} x (lzf_table_offset_batch + lzf_compress_batch of {S} jobs)"
+    return {
+        "metric": METRIC, "value": gib(tot * args.steps, d_el), "unit": "GiB/s (uncompressed bytes decompressed per second; linked 64 KiB blocks behind a dictionary)",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(d_el / args.steps * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "config5: %d streams x 1 MiB per GPU, each a 256-byte motif of its own repeated, framed as 64 KiB LINKED blocks behind a "
+                               "64 KiB dictionary of the motif (U32Table, table and window carried on the device, block k of every stream in launch k); "
+                               "lz4 ratio %.0f" % (S, N1 / max(C1, 1.0)),
+                   "streams_per_gpu": S, "block_size": B5, "blocks_per_stream": NB, "dictionary_bytes": DL, "template_seed_ms_untimed": round(seed_ms, 1),
+                   "verified_against_oracle": verified, "parallelism": f"streams x{world}, no collective (linked streams do not shard: replicas only)"},
+        "roofline": r_d,
+        "compress": {"value": gib(tot * args.steps, c_el), "unit": "GiB/s (uncompressed bytes compressed per second)", "ms_per_step": round(c_el / args.steps * 1e3, 3), "roofline": r_c},
+        "u16_raw": {"jobs": int(NU), "slice_bytes": 65535,
+                    "compress": {"value": gib(float(NU) * 65535 * world * args.steps, u_el), "unit": "GiB/s", "ms_per_step": round(u_el / args.steps * 1e3, 3),
+                                 "roofline": roof(float(NU) * 65535 + float(ures["out_len"].sum()), u_ms, "lzf_compress_wave_kernel<U16>")},
+                    "decompress": {"value": gib(float(NU) * 65535 * world * args.steps, ud_el), "unit": "GiB/s", "ms_per_step": round(ud_el / args.steps * 1e3, 3),
+                                   "roofline": roof(float(NU) * 65535 + float(ures["out_len"].sum()), ud_ms, lib.lzf_last_decompress_launch().decode())}},
     }
 
 
