@@ -287,7 +287,8 @@ def main():
                 line["config4"] = {"value": l4["value"], "unit": l4["unit"], "scaling": "strong", "steps": a4.steps, "ms_per_step": l4["ms_per_step"],
                                    "compress_ms": l4["roofline"]["kernel_ms"], "gather_ms": l4["config"]["gather_ms"],
                                    "wire_bytes_in_per_rank": l4["config"]["wire_bytes_in_per_rank"], "frame_bytes": l4["config"]["frame_bytes"],
-                                   "n_ranks_seen_by_rccl": l4["config"]["n_ranks_seen_by_rccl"], "blocks": l4["config"]["blocks"],
+                                   "n_ranks_seen_by_rccl": l4["config"]["n_ranks_seen_by_rccl"], "gather_path": l4["config"]["gather_path"], "blocks": l4["config"]["blocks"],
+                                   "compress_launch": l4["roofline"]["kernel"],
                                    "verified_against_oracle_prefix": l4["config"]["verified_against_oracle_prefix"],
                                    "content_checksum": l4["config"]["content_checksum"]}
         if not args.no_config5 and world == 1:
@@ -614,6 +615,23 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
     state = {}
     header = lzdist.frame_header(content_checksum=False, block_size=BS)
 
+    # the exchange under the C ABI (include/lzfear_dist.h: lzf_frame_gather over an RCCL communicator of its own, bootstrapped by
+    # broadcasting rank 0's ncclUniqueId over the process group); torch.distributed's P2P path stays as the fallback
+    comm, gather_path = None, "torch.distributed (all_gather_into_tensor + batch_isend_irecv)"
+    if os.environ.get("LZF_GATHER", "c") != "torch":
+        try:
+            comm = lzdist.DistComm(dist, rank, world, dev)
+            gather_path = "lzf_frame_gather (C ABI, liblzfear_dist.so: ncclAllGather + grouped ncclSend / ncclRecv)"
+        except Exception as e:      # noqa: BLE001 — a first multi-rank run must not die in new code
+            log(f"[bench] rank {rank}: lzf_dist_comm_init failed ({e}); falling back to torch.distributed")
+            gather_path += f" [fallback: {e}]"
+    if dist and world > 1:      # every rank takes the same path
+        flag = torch.tensor([1 if comm else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag[0]) == 0 and comm:
+            comm.close(); comm = None
+            gather_path = "torch.distributed (all_gather_into_tensor + batch_isend_irecv) [fallback: another rank could not make the communicator]"
+
     kev, gev = [], []
 
     def step():
@@ -623,7 +641,10 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
         state["launch"] = ffi.lib().lzf_last_compress_launch().decode()
         b.record()
         kev.append((a, b))
-        state["frame_len"], state["comp_total"] = lzdist.gather_frame_device(d_cres, comp, src, BS, nloc, nblk_all, frame, dist, rank, world, device, header)
+        if comm:
+            state["frame_len"], state["comp_total"] = lzdist.gather_frame_device_c(comm, d_cres, comp, src, BS, nloc, nblk_all, frame, header)
+        else:
+            state["frame_len"], state["comp_total"] = lzdist.gather_frame_device(d_cres, comp, src, BS, nloc, nblk_all, frame, dist, rank, world, device, header)
         c2.record()
         gev.append((b, c2))
 
@@ -669,6 +690,9 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
         body = ref[:-4]                                                # (without the oracle frame's EndMark)
         verified = mine[: len(body)] == body
         assert verified, "sharded frame differs from the oracle's frame on the first blocks"
+    n_seen = comm.count() if comm else (dist.get_world_size() if dist else 0)
+    if comm:
+        comm.close()
     if rank != 0:
         return None
     total_bytes = float(nblk_all) * BS
@@ -698,7 +722,8 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
                                (nblk_all, total_bytes / 2**30, total_bytes / max(state["comp_total"], 1)),
                    "blocks": nblk_all, "block_size": BS, "parallelism": f"block ranges x{world}, all-gather over RCCL",
                    "frame_bytes": int(state["frame_len"]), "wire_bytes_in_per_rank": int(wire), "verified_against_oracle_prefix": verified,
-                   "gather_ms": round(g_ms, 3), "n_ranks_seen_by_rccl": (dist.get_world_size() if dist else 0), "content_checksum": xx},
+                   "gather_ms": round(g_ms, 3), "gather_path": gather_path,
+                   "n_ranks_seen_by_rccl": n_seen, "content_checksum": xx},
         "roofline": {"bound": "hbm", "kernel": state["launch"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_for("lzf_compress_compact_kernel<false>", "compress", nloc)[0],
                      "algorithmic_bytes_per_launch": alg, "kernel_ms": round(k_ms, 4)},

@@ -102,6 +102,30 @@ def build_library(force=False, verbose=False, defines=(), out=None, analysis=Fal
     return out
 
 
+DIST_LIB_PATH = os.path.join(PKG_DIR, "liblzfear_dist.so")
+
+
+def build_dist_library(force=False, verbose=False):
+    """liblzfear_dist.so: the frame reassembly of the block-sharded compressor over RCCL (include/lzfear_dist.h, csrc/dist_gather.hip).
+    Its own library so that the codec library keeps depending on libamdhip64 alone; links librccl and liblzfear_hip."""
+    core = build_library(force=False, verbose=verbose)
+    src = _path("dist_gather.hip")
+    deps = [src, os.path.join(ROOT, "include", "lzfear_dist.h"), os.path.join(ROOT, "include", "lzfear_hip.h")]
+    out = DIST_LIB_PATH
+    if not force and os.path.exists(out) and os.path.getmtime(out) >= max(os.path.getmtime(d) for d in deps):
+        LAST_BUILD[out] = "reused (the library is newer than every source and header)"
+    else:
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"), "-o", out, src,
+               "-L", os.path.dirname(core), "-l:" + os.path.basename(core), "-L", "/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN", "-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+        LAST_BUILD[out] = "compiled dist_gather.hip with hipcc --offload-arch=gfx950, linked against librccl + liblzfear_hip"
+    if verbose:
+        print(f"[build] {os.path.basename(out)}: {LAST_BUILD[out]}", flush=True)
+    return out
+
+
 def build_analysis_library(force=False, verbose=False):
     return build_library(force=force, verbose=verbose, analysis=True)
 

@@ -154,3 +154,75 @@ def gather_frame_device(d_cres, comp, src, block_size, n_local, n_blocks, frame,
     frame[flen - 4:flen] = 0                                       # EndMark (no content checksum in this mode)
     comp_total = int(sum(seg_host)) - 4 * n_blocks
     return flen, comp_total
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The same exchange under the C ABI (include/lzfear_dist.h, liblzfear_dist.so: ncclAllGather of the size words, in-place packing,
+# grouped ncclSend / ncclRecv of the exact-size segments) — what a Rust / C host calls.  Python only bootstraps the communicator:
+# rank 0's ncclUniqueId travels over the process group that already exists.
+# ------------------------------------------------------------------------------------------------------------------
+_dist_lib = None
+
+
+def dist_lib():
+    """liblzfear_dist.so (built by __graft_entry__.build(); links librccl — in a torch process the loader binds it to the RCCL torch loaded)."""
+    global _dist_lib
+    if _dist_lib is None:
+        import os
+        from . import build as _build
+        ffi.lib()                                             # liblzfear_hip.so first: the dist library needs it
+        path = _build.DIST_LIB_PATH
+        if not os.path.exists(path):
+            raise ffi.LzfError(ffi.E_INVALID, f"{path} is missing — run __graft_entry__.build()")
+        L = C.CDLL(path)
+        L.lzf_dist_last_error.restype = C.c_char_p
+        L.lzf_dist_unique_id.argtypes = [C.c_char_p]
+        L.lzf_dist_comm_init.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.lzf_dist_comm_count.argtypes = [C.c_void_p]
+        L.lzf_dist_comm_free.argtypes = [C.c_void_p]
+        L.lzf_frame_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
+                                       C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p]
+        _dist_lib = L
+    return _dist_lib
+
+
+class DistComm:
+    """lzf_dist_comm: an RCCL communicator made through the C ABI.  `dist_mod` (torch.distributed, initialised) only carries rank 0's
+    ncclUniqueId to the other ranks; None = a single rank."""
+
+    def __init__(self, dist_mod, rank, world, device):
+        L = dist_lib()
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            rc = L.lzf_dist_unique_id(uid)
+            if rc != 0:
+                raise ffi.LzfError(rc, L.lzf_dist_last_error().decode())
+        if world > 1:
+            t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).to(device)
+            dist_mod.broadcast(t, src=0)
+            uid = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
+        self.handle = C.c_void_p()
+        rc = L.lzf_dist_comm_init(uid, rank, world, C.byref(self.handle))
+        if rc != 0:
+            raise ffi.LzfError(rc, L.lzf_dist_last_error().decode())
+        self.rank, self.world = rank, world
+
+    def count(self):
+        return dist_lib().lzf_dist_comm_count(self.handle)
+
+    def close(self):
+        if self.handle:
+            dist_lib().lzf_dist_comm_free(self.handle)
+            self.handle = C.c_void_p()
+
+
+def gather_frame_device_c(comm, d_cres, comp, src, block_size, n_local, n_blocks, frame, header, last_block_len=None, stream=None):
+    """gather_frame_device through lzf_frame_gather (include/lzfear_dist.h).  Returns (frame bytes, total compressed payload bytes)."""
+    flen, ctot = C.c_uint64(0), C.c_uint64(0)
+    st = (stream or torch.cuda.current_stream()).cuda_stream
+    rc = dist_lib().lzf_frame_gather(comm.handle, d_cres.data_ptr(), comp.data_ptr(), src.data_ptr(), block_size, block_size, n_local, n_blocks,
+                                     block_size if last_block_len is None else last_block_len, bytes(header), len(header), frame.data_ptr(), frame.numel(),
+                                     C.byref(flen), C.byref(ctot), st)
+    if rc != 0:
+        raise ffi.LzfError(rc, dist_lib().lzf_dist_last_error().decode())
+    return int(flen.value), int(ctot.value)

@@ -37,6 +37,23 @@ def test_library_exports_every_declared_symbol(lib):
     assert sorted(declared_functions("lzfear_frame.h")) == sorted(ffi.FRAME_EXPORTS)
 
 
+def test_dist_library_exports_every_declared_symbol():
+    """include/lzfear_dist.h (the block-sharded frame's exchange over RCCL) is what liblzfear_dist.so exports; the codec library
+    itself does not depend on RCCL."""
+    import subprocess
+    from rust_lz_fear_amd import dist as lzdist
+    path = build.build_dist_library()
+    names = declared_functions("lzfear_dist.h")
+    assert "lzf_frame_gather" in names and "lzf_dist_comm_init" in names
+    L = lzdist.dist_lib()
+    for name in names:
+        assert hasattr(L, name), name
+    needed = subprocess.run(["readelf", "-d", path], capture_output=True, text=True).stdout
+    assert "librccl" in needed and "liblzfear_hip" in needed
+    core = subprocess.run(["readelf", "-d", build.build_library()], capture_output=True, text=True).stdout
+    assert "rccl" not in core
+
+
 def test_frame_layer_host_only_pieces(lib):
     """Header parsing, XXH32 and frame assembly are pure host code: usable without a GPU."""
     import ctypes as C

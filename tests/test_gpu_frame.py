@@ -399,6 +399,47 @@ def test_gather_frame_device_nccl_world1():
         dist.destroy_process_group()
 
 
+def test_frame_gather_c_abi_rccl_world1():
+    """The same exchange under the C ABI (include/lzfear_dist.h, liblzfear_dist.so): lzf_dist_unique_id / lzf_dist_comm_init make an RCCL
+    communicator of one rank (no torch.distributed involved), lzf_frame_gather runs the size-table all-gather path, the in-place
+    packing kernel + lzf_copy_ranges, header and EndMark: the WHOLE frame equals the oracle's — a stored block and a short last
+    block included — ncclCommCount says 1, and a status that cannot be framed is refused."""
+    import torch
+    from rust_lz_fear_amd import device, ffi, dist as lzdist
+    BS = 4 << 20
+    data = np.concatenate([synth.log_text(0, 2 * BS), np.frombuffer(vectors.rng_bytes(5, BS), np.uint8),
+                           synth.log_text(2 * BS, 3 * BS + 777_777)])
+    d_in = torch.from_numpy(data).cuda()
+    blocks = device.BlockSet(d_in, BS); n = blocks.n
+    d_out = torch.empty(n * BS, dtype=torch.uint8, device="cuda")
+    d_res = torch.zeros(n * 16, dtype=torch.uint8, device="cuda")
+    device.compress_batch(device.to_device(blocks.compress_jobs(d_out, BS), "cuda"), d_res, n)
+    torch.cuda.synchronize()
+    res = device.results_to_host(d_res, n)
+    assert ffi.OUTPUT_FULL in set(int(x) for x in res["status"])              # the random block is stored
+    comm = lzdist.DistComm(None, 0, 1, "cuda")
+    try:
+        assert comm.count() == 1
+        frame = torch.zeros(64 + n * (BS + 8), dtype=torch.uint8, device="cuda")
+        header = lzdist.frame_header(content_checksum=False, block_size=BS)
+        flen, ctot = lzdist.gather_frame_device_c(comm, d_res, d_out, d_in, BS, n, n, frame, header, last_block_len=int(blocks.lens[-1]))
+        mine = frame[:flen].cpu().numpy().tobytes()
+        raw = data.tobytes()
+        rc, ref = o.frame_compress(raw, o.make_settings(block_size=BS, content_checksum=False))
+        assert rc == 0 and mine == ref
+        assert ctot == sum(int(l) if st == 0 else int(rl) for l, st, rl in zip(res["out_len"], res["status"], blocks.lens))
+        assert framed.decompress_frame(mine) == raw
+        # a frame buffer that is too small, and a status that is neither OK nor OUTPUT_FULL
+        with pytest.raises(ffi.LzfError):
+            lzdist.gather_frame_device_c(comm, d_res, d_out, d_in, BS, n, n, frame[:1000], header, last_block_len=int(blocks.lens[-1]))
+        bad = res.copy(); bad["status"][1] = ffi.CONTRACT
+        d_bad = device.to_device(bad, "cuda")
+        with pytest.raises(ffi.LzfError):
+            lzdist.gather_frame_device_c(comm, d_bad, d_out, d_in, BS, n, n, frame, header, last_block_len=int(blocks.lens[-1]))
+    finally:
+        comm.close()
+
+
 # ---------------------------------------------------------------- many frames per call
 def _frame_inputs():
     mix = synth.silesia_mix(20 << 20, (20 << 20) + 900_000).tobytes()
