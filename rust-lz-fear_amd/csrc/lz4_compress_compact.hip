@@ -215,7 +215,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 // the batch is the lanes below D: a winner among them ends the run, otherwise they commit and the next batch
                 // starts at lane D's position (D >= 1).
                 const uint32_t D = first_lane(__ballot(first != lane));
-                uint32_t W = 64u, cand = 0; uint64_t B0 = 0, B1 = 0, PA = 0, PB = 0;
+                uint32_t W = 64u, cand = 0, B4 = 0;
                 {
                     const uint32_t s16 = (h & 1u) ? oldpair >> 16 : oldpair & 0xFFFFu;
                     const uint32_t ec = c >> 16, xk = ck & 0xFFFFu;
@@ -229,26 +229,11 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                         : "=&v"(gt), "=&v"(inr) : "v"(xk), "v"(s16), "v"(lane), "s"(dcut));
                     const uint32_t okv = ((gt & e1 & diff) | ((gt ^ 1u) & (diff ^ 1u))) & inr;   // <=> in the batch, cand <= ck && ck - cand <= 0xFFFF
                     const bool reach = okv != 0u;
-                    // The 8 bytes before a probe (backtrack, :211-212).  In a run's first batch the backtrack of lane k stops after k
-                    // bytes (:211: cursor - literal_start), so only input[ls .. ls + k) matters — and that is in the lanes' registers:
-                    // lane k >= 8 takes lane k - 8's probe bytes, lane k < 8 the run's first k bytes in the top of the word (the rest
-                    // is never looked at: the bound cuts it off).  One load fewer per sequence; worked out behind the gather's issue.
-                    static_assert(kFirstBatch <= 16u, "pa_regs: row_shr:8 stays inside a DPP row of 16 lanes — a wider first batch needs a cross-row fetch");
-                    const bool pa_regs = n == 0u;
-                    if (reach) {
-                        B0 = ld8(in + cand); B1 = ld8(in + cand + 8u);
-                        if (!pa_regs) PA = ld8(in + ck - 8u);
-                        PB = ld8(in + ((cand - 8u) & (0u - lt01(7u, cand))));   // (unused when cand < 8)
-                    }
+                    // candidate side: the 4 bytes of the accept test (:204-206) and nothing else — the match is measured by the whole
+                    // wave once the winner is known (below), not worked out by every lane for its own candidate
+                    if (reach) B4 = ld4(in + cand);
                     flush_ps();                       // (the previous sequence's store: behind this batch's gather)
-                    if (pa_regs) {
-                        const uint32_t lo = (uint32_t)A0, hi = (uint32_t)(A0 >> 32);
-                        const uint32_t slo = LZF_DPP(0, lo, 0x118 /* row_shr:8 */, 0xf), shi = LZF_DPP(0, hi, 0x118, 0xf);
-                        const uint64_t first8 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)hi, 0) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)lo, 0);
-                        const uint32_t k7 = lane & 7u;
-                        PA = (lane & 8u) ? (((uint64_t)shi << 32) | slo) : (first8 << ((8u - k7) * 8u - (k7 ? 0u : 1u)));
-                    }
-                    const bool valid = reach && (uint32_t)A0 == (uint32_t)B0;  // :204-206 (m >= 4)
+                    const bool valid = reach && (uint32_t)A0 == B4;            // :204-206 (m >= 4)
                     W = first_lane(__ballot(valid));
                     CPHASE(0);
                     {
@@ -265,24 +250,20 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     }
                 }
                 if (W < 64u) {
-                    // Every lane works out the match as if it were the winner — in vector registers — and the winner's packed
-                    // answer is read with one v_readlane: the scalar unit sees a handful of instructions instead of ~150.
-                    // (Here len - ck >= 56: the forward bound :195 cannot cut the 16 compared bytes, and `cursor - 2` has its 8 bytes.)
-                    const uint64_t x0 = A0 ^ B0, x1 = A1 ^ B1;
-                    const uint32_t m_loc = x0 ? (uint32_t)(__builtin_ctzll(x0) >> 3) : 8u + (x1 ? (uint32_t)(__builtin_ctzll(x1) >> 3) : 8u);   // 4..16
-                    const uint64_t xp = PA ^ PB;
-                    const uint32_t bt_loc = xp ? (uint32_t)(__builtin_clzll(xp) >> 3) : 8u;
-                    const uint32_t bf = lt01(7u, cand);                                    // btfast
-                    const uint32_t runlen = ck - ls;
-                    const uint32_t mb = runlen < cand ? runlen : cand;                     // :211-212 bounds
-                    const uint32_t btq = bt_loc < mb ? bt_loc : mb;
-                    const uint32_t bt_k = btq & (0u - bf);
-                    const uint32_t more_bt_k = (bf & (bt_loc >> 3) & lt01(8u, mb)) | ((bf ^ 1u) & lt01(0u, mb));
-                    const uint32_t pk = m_loc | (bt_k << 5) | (more_bt_k << 9);
-                    const uint32_t wpk = __builtin_amdgcn_readlane(pk, W);
+                    // The match, measured by the wave (round 5, from the team kernel): lanes 0..31 compare bytes 4..35 forwards (:203-204;
+                    // here len - ck >= 56: the bound :195 cannot cut them), lanes 32..63 bytes 1..32 backwards, bounded by the run and the
+                    // input's start (:211-212) — two byte loads per lane from lines the gather and the probes just touched, one ballot,
+                    // two s_ff1, instead of 24 gathered bytes per lane and ~60 instructions of 64-bit arithmetic, packing and unpacking.
                     m_pos = c + W;
                     m_cand = __builtin_amdgcn_readlane(cand, W);
-                    const uint32_t wm = wpk & 31u, wbt = (wpk >> 5) & 15u;
+                    const uint32_t runl = m_pos - ls, maxbt = runl < m_cand ? runl : m_cand;
+                    const uint32_t li = lane & 31u;
+                    const bool bwd = lane >= 32u, okb = li < maxbt;
+                    const uint32_t oa = bwd ? (okb ? 0u - 1u - li : 0u) : 4u + li;          // (a backward lane beyond the bound reads a harmless byte)
+                    const uint32_t xa = in[m_pos + oa], xb = in[m_cand + oa];
+                    const unsigned long long mk = __ballot(xa != xb || (bwd && !okb));
+                    const uint32_t mlo = (uint32_t)mk, mhi = (uint32_t)(mk >> 32);
+                    const uint32_t wm = mlo ? 4u + (uint32_t)__builtin_ctz(mlo) : 36u, wbt = mhi ? (uint32_t)__builtin_ctz(mhi) : 32u;
                     // table.replace(input, cursor - 2) (:218): the 8 bytes at cursor - 2 are the probe bytes of lane W + m - 2, whose
                     // hash is already there (lanes up to `have` hold probe bytes; an extended match is handled at the insert)
                     const uint32_t qi = W + wm - 2u;
@@ -295,7 +276,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     const uint32_t nl2 = L2 >= 15u ? 1u : 0u;                          // literal length beyond the token: one LSIC byte up to 57
                     const int32_t inrange = (int32_t)(have - 1u - qi) | (int32_t)(f_hi - kFirstBatch - cur2) | (int32_t)(14u - ex2) |
                                             (int32_t)(57u - L2) | (int32_t)(s.cap - s.pos - (L2 + 3u + nl2));
-                    if ((wpk & 0x210u) == 0u && inrange >= 0) {
+                    if (mlo != 0u && mhi != 0u && inrange >= 0) {
                         if (DRY) ++work;
                         cursor = cur2;                                                 // :215
                         // lane j: literal j - 1 - nl2.  A run that ends in its first batch has them in registers — lane k probed
@@ -324,9 +305,9 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                         straight = true;
                     } else {
                         m = wm;
-                        more_m = m >= 16u;
+                        more_m = mlo == 0u;
                         bt = wbt;
-                        more_bt = ((wpk >> 9) & 1u) != 0u;
+                        more_bt = mhi == 0u;
                         if (!more_m && qi < have) ins_h = __builtin_amdgcn_readlane(h, qi);
                     }
                     return true;
@@ -336,20 +317,28 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             if (!fast_batch(kFirstBatch))
                 while (n < 58u) { if (fast_batch(66u - n < 48u ? 66u - n : 48u)) break; }
             if (straight) continue;
-            // An extended match of the fast search (all 16 compared bytes equal, m == 16 so far) that ends within the next 512
-            // bytes, with a short literal run, also goes in a straight line: one compare round of 8 bytes per lane (:203-204),
-            // the length's LSIC tail (mod.rs:243-260) in the same store, the `cursor - 2` insert deferred to the top of the next
-            // iteration like in the general tail.  (Kept out of the search loop: inside it, it costs the common path scalar moves.)
-            if (found && more_m && !more_bt && m == 16u && m_pos + 16u + 512u + 5u <= len) {
+            // A match of the fast search that the straight line above did not finish — longer than the token holds (a length tail,
+            // mod.rs:243-260), or all 32 measured bytes equal (m == 36 so far) and ending within the next 512 bytes — with a short
+            // literal run, also goes in a straight line: if needed one compare round of 8 bytes per lane (:203-204), the length's LSIC
+            // tail in the same store, the `cursor - 2` insert deferred to the top of the next iteration like in the general tail.
+            // (Kept out of the search loop: inside it, it costs the common path scalar moves.)
+            if (found && !more_bt && (!more_m || (m == 36u && m_pos + 36u + 512u + 5u <= len))) {
                 const uint32_t L3 = (m_pos - bt) - ls;
                 if (L3 < 15u) {
-                    const uint64_t x = ld8(in + m_pos + 16u + lane * 8u) ^ ld8(in + m_cand + 16u + lane * 8u);
-                    const unsigned long long neq = __ballot(x != 0ull);
-                    if (neq) {
-                        const uint32_t fl = (uint32_t)__builtin_ctzll(neq);
-                        const uint32_t xlo = __builtin_amdgcn_readlane((uint32_t)x, fl), xhi = __builtin_amdgcn_readlane((uint32_t)(x >> 32), fl);
-                        const uint32_t me = 16u + fl * 8u + (uint32_t)(__builtin_ctzll(((uint64_t)xhi << 32) | xlo) >> 3);
-                        const uint32_t cur3 = m_pos + me, ex3 = me - 4u + bt;                          // ex3 in 12 .. 531
+                    uint32_t me = m;
+                    bool have_me = !more_m;
+                    if (more_m) {
+                        const uint64_t x = ld8(in + m_pos + 36u + lane * 8u) ^ ld8(in + m_cand + 36u + lane * 8u);
+                        const unsigned long long neq = __ballot(x != 0ull);
+                        if (neq) {
+                            const uint32_t fl = (uint32_t)__builtin_ctzll(neq);
+                            const uint32_t xlo = __builtin_amdgcn_readlane((uint32_t)x, fl), xhi = __builtin_amdgcn_readlane((uint32_t)(x >> 32), fl);
+                            me = 36u + fl * 8u + (uint32_t)(__builtin_ctzll(((uint64_t)xhi << 32) | xlo) >> 3);
+                            have_me = true;
+                        }
+                    }
+                    if (have_me) {
+                        const uint32_t cur3 = m_pos + me, ex3 = me - 4u + bt;                          // ex3 in 0 .. 575
                         const uint32_t nt = ex3 < 15u ? 0u : 1u + (ex3 >= 270u ? 1u : 0u) + (ex3 >= 525u ? 1u : 0u);   // lsic_len
                         const uint32_t tot3 = L3 + 3u + nt;
                         if (cur3 + kFirstBatch <= f_hi && s.cap - s.pos >= tot3) {
