@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
         // The first batch of a literal run probes cursor + lane; those 16 bytes per lane are requested
         // as soon as the cursor is known (before the previous sequence is emitted) and consumed here.
         uint32_t pf_c = 0xFFFFFFFFu;
-        uint64_t pfA0 = 0, pfA1 = 0;
+        uint64_t pfA0 = 0;        // (8 bytes per lane; lanes that were not loaded keep stale bytes: every use of a lane's hash is guarded by its being in the batch)
         uint32_t pend_q = 0xFFFFFFFFu;      // position of a `cursor - 2` insert whose bytes (pfQ, lane 16) are in flight
         uint64_t pfQ = 0;
         auto insert_hash = [&](uint32_t q, uint32_t h) {       // lane 0 writes the slot, the others their scratch word
@@ -163,6 +163,15 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             lds_mskor32(tab_a + 4u * pa, bit, bit & (0u - ((q >> 16) & 1u)));      // the slot's parity bit := parity of q's epoch
         };
         auto insert_at = [&](uint32_t q, uint64_t v8) { insert_hash(q, hash5(v8)); };
+        // The same when lane `qi` of the wave probed position q itself, i.e. holds its hash in h: that lane alone makes the two accesses
+        // (EXEC narrowed to it around them; every lane is active here, the kernel's control flow is wave-uniform) with addresses it
+        // has mostly worked out for the commit already — 8 instructions instead of the 18 of a v_readlane'd hash spread back to lane 0.
+        auto insert_from_lane = [&](uint32_t qi, uint32_t q, uint32_t h) {
+            const uint32_t a16 = tab_a + 2u * h, pa = tab_a + 4u * (kParBase + (h >> 5)), bit = 1u << (h & 31u);
+            const uint32_t val = bit & (0u - ((q >> 16) & 1u));
+            asm volatile("s_mov_b64 exec, %0\n\tds_write_b16 %1, %2\n\tds_mskor_b32 %3, %4, %5\n\ts_mov_b64 exec, -1"
+                         ::"s"(1ull << qi), "v"(a16), "v"(q), "v"(pa), "v"(bit), "v"(val) : "memory");
+        };
 #ifdef LZF_PHASE_TIMING
         long long tq = clock64();
 #define CPHASE(i) do { const long long tn = clock64(); g_tph[i] += tn - tq; tq = tn; } while (0)
@@ -201,9 +210,9 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 const bool inb = lane < bw;
                 const uint32_t ck = c + lane;
                 const uint32_t have = bw > kProbeLanes ? bw : kProbeLanes;   // lanes holding 16 input bytes (c + 40 + bw <= len: readable)
-                uint64_t A0 = 0, A1 = 0;
-                if (pf_c == c) { A0 = pfA0; A1 = pfA1; }                  // (only a run's first batch: pf_c is cleared below)
-                else if (lane < have) { A0 = ld8(in + ck); A1 = ld8(in + ck + 8u); }
+                // (a run's first batch finds its probe bytes requested by the previous sequence; a scalar branch, not a per-lane select)
+                if (pf_c != c) { if (lane < have) pfA0 = ld8(in + ck); }
+                const uint64_t A0 = pfA0;
                 pf_c = 0xFFFFFFFFu;
                 const uint32_t h = hash5(A0);
                 const uint32_t wi = inb ? h >> 1 : kScratch + lane;          // (lanes outside the batch: their scratch word)
@@ -290,10 +299,9 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                             const uint32_t lt = lane > nl2 ? lane - nl2 : 0u, lj = lt < L2 ? lt : L2;
                             byte = in[ls + (lj ? lj - 1u : 0u)];
                         }
-                        pfA0 = 0; pfA1 = 0;                                            // the next run's probe bytes, right behind
-                        if (lane < kProbeLanes) { pfA0 = ld8(in + cur2 + lane); pfA1 = ld8(in + cur2 + lane + 8u); }
+                        if (lane < kProbeLanes) pfA0 = ld8(in + cur2 + lane);          // the next run's probe bytes, right behind
                         pf_c = cur2;
-                        insert_hash(cur2 - 2u, __builtin_amdgcn_readlane(h, qi));     // :218
+                        insert_from_lane(qi, cur2 - 2u, h);                            // :218 (lane qi probed cursor - 2: have - 1 - qi >= 0 above)
                         const uint32_t off2 = m_pos - m_cand;                          // :208
                         if (lane == 1u && nl2) byte = L2 - 15u;                        // write_group, :150-163
                         if (lane == 0u) byte = ((nl2 ? 15u : L2) << 4) | ex2;
@@ -346,8 +354,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                             cursor = cur3;                                                 // :215
                             const uint32_t lj = lane < L3 ? lane : L3;
                             uint32_t byte = in[ls + (lj ? lj - 1u : 0u)];                // lane j: literal j-1
-                            pfA0 = 0; pfA1 = 0;
-                            if (lane < kProbeLanes) { pfA0 = ld8(in + cur3 + lane); pfA1 = ld8(in + cur3 + lane + 8u); }
+                            if (lane < kProbeLanes) pfA0 = ld8(in + cur3 + lane);
                             pf_c = cur3;
                             if (lane == 16u) pfQ = ld8(in + cur3 - 2u);                   // :218, inserted before the next probes
                             pend_q = cur3 - 2u;
@@ -390,7 +397,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 const bool epk = easy ? false : (inb && (ck >> 16) != (c >> 16));     // beyond the epoch of the batch base: next batch
                 const bool active = inb && !endk && !epk;
                 uint64_t A0 = 0, A1 = 0;                                  // input[ck .. ck+16)
-                if (n == 0u && pf_c == c) { A0 = pfA0; A1 = pfA1; }
+                if (n == 0u && pf_c == c) { A0 = pfA0; if (easy) { if (inb) A1 = ld8(in + ck + 8u); } else if (active) A1 = ld8_part(ck + 8u); }
                 else if (easy) { if (inb) { A0 = ld8(in + ck); A1 = ld8(in + ck + 8u); } }
                 else if (active) { A0 = ld8(in + ck); A1 = ld8_part(ck + 8u); }   // >= 12 bytes remain
                 pf_c = 0xFFFFFFFFu;
@@ -588,9 +595,8 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
             }
             {
                 const uint32_t ckn = cursor + lane;
-                pfA0 = 0; pfA1 = 0;
-                if (cursor + kFirstBatch + 40u <= len) { if (lane < kProbeLanes) { pfA0 = ld8(in + ckn); pfA1 = ld8(in + ckn + 8u); } }   // (16 probes + the bytes behind them)
-                else if (lane < kFirstBatch && ckn <= len && len - ckn >= 12u) { pfA0 = ld8(in + ckn); pfA1 = ld8_part(ckn + 8u); }
+                if (cursor + kFirstBatch + 40u <= len) { if (lane < kProbeLanes) pfA0 = ld8(in + ckn); }   // (16 probes + the 16 positions behind them: the `cursor - 2` insert's hash)
+                else if (lane < kFirstBatch && ckn <= len && len - ckn >= 12u) pfA0 = ld8(in + ckn);
                 pf_c = cursor;
             }
             // table.replace(input, cursor - 2) — unconditional (:218, quirks B1/B3).  When the 8 bytes at cursor - 2 are
