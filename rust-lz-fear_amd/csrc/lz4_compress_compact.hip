@@ -185,7 +185,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 insert_at(pend_q, v8);
                 pend_q = 0xFFFFFFFFu;
             }
-            const uint32_t ls = cursor;                                   // :172 literal_start
+            uint32_t ls = cursor;                                         // :172 literal_start
             uint32_t n = 0;          // probe index inside this literal run
             uint32_t c = cursor;     // position of probe n
             bool finished = false;   // last-literals path taken
@@ -232,12 +232,11 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     //  instructions, and the scalar unit is what the compress kernels run out of)
                     const uint32_t diff = ((pw >> (h & 31u)) ^ ec) & 1u;              // 1: the slot's epoch is the previous one
                     cand = ((ec - diff) << 16) | s16;
-                    const uint32_t e1 = ec >= 1u ? 1u : 0u, dcut = D < bw ? D : bw;
-                    uint32_t gt, inr;                                                     // s16 > xk; lane < dcut  (all < 2^16)
-                    asm("v_sub_u32 %0, %2, %3\n\tv_lshrrev_b32 %0, 31, %0\n\tv_sub_u32 %1, %4, %5\n\tv_lshrrev_b32 %1, 31, %1"
-                        : "=&v"(gt), "=&v"(inr) : "v"(xk), "v"(s16), "v"(lane), "s"(dcut));
-                    const uint32_t okv = ((gt & e1 & diff) | ((gt ^ 1u) & (diff ^ 1u))) & inr;   // <=> in the batch, cand <= ck && ck - cand <= 0xFFFF
-                    const bool reach = okv != 0u;
+                    const uint32_t dcut = D < bw ? D : bw;
+                    // in the batch, cand <= ck && ck - cand <= 0xFFFF (:200-201) as ONE unsigned compare: a candidate behind ck wraps to a
+                    // huge distance.  (ec == 0 with diff == 1 — "the epoch before the first" — cannot occur: in epoch 0 every parity bit is 0,
+                    // table-in and sweep_to above.)
+                    const bool reach = lane < dcut && ck - cand <= 0xFFFFu;
                     // candidate side: the 4 bytes of the accept test (:204-206) and nothing else — the match is measured by the whole
                     // wave once the winner is known (below), not worked out by every lane for its own candidate
                     if (reach) B4 = ld4(in + cand);
@@ -322,7 +321,17 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 }
                 return false;
             };
-            if (!fast_batch(kFirstBatch))
+            // The straight sequences of consecutive runs as a loop of their own (round 5): its only loop-carried state is the cursor, the
+            // sink, the deferred store and the prefetched probe bytes — as part of the big loop every iteration paid a dozen scalar moves
+            // that merge its control flow with the rare paths'.  (A straight sequence leaves cursor + 16 <= f_hi, no pending insert.)
+            bool fast_over;
+            for (;;) {
+                fast_over = fast_batch(kFirstBatch);
+                if (!straight) break;
+                straight = false; found = false;
+                ls = cursor; c = cursor; n = 0;
+            }
+            if (!fast_over)
                 while (n < 58u) { if (fast_batch(66u - n < 48u ? 66u - n : 48u)) break; }
             if (straight) continue;
             // A match of the fast search that the straight line above did not finish — longer than the token holds (a length tail,
