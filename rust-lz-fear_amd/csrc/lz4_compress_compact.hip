@@ -107,7 +107,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     const uint32_t e = v >> 16;
                     const bool keep = e == e0 || e + 1u == e0;             // within reach of the first probes
                     tab16[i] = keep ? (uint16_t)v : (uint16_t)0;
-                    const unsigned long long bm = __ballot(keep ? (e & 1u) != 0u : gone_par != 0u);
+                    const unsigned long long bm = __builtin_amdgcn_ballot_w64(keep ? (e & 1u) != 0u : gone_par != 0u);
                     if (lane == 0) { par[i >> 5] = (uint32_t)bm; par[(i >> 5) + 1u] = (uint32_t)(bm >> 32); }
                 }
             } else {
@@ -223,8 +223,8 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 // their candidates are what the sequential code would see, and their table writes are the sequential ones.  So
                 // the batch is the lanes below D: a winner among them ends the run, otherwise they commit and the next batch
                 // starts at lane D's position (D >= 1).
-                const uint32_t D = first_lane(__ballot(first != lane));
-                uint32_t W = 64u, cand = 0, B4 = 0;
+                const uint32_t D = first_lane(__builtin_amdgcn_ballot_w64(first != lane));
+                uint32_t W = 64u, cand = 0;
                 {
                     const uint32_t s16 = (h & 1u) ? oldpair >> 16 : oldpair & 0xFFFFu;
                     const uint32_t ec = c >> 16, xk = ck & 0xFFFFu;
@@ -239,10 +239,10 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     const bool reach = lane < dcut && ck - cand <= 0xFFFFu;
                     // candidate side: the 4 bytes of the accept test (:204-206) and nothing else — the match is measured by the whole
                     // wave once the winner is known (below), not worked out by every lane for its own candidate
+                    uint32_t B4 = ~(uint32_t)A0;      // (a lane without a candidate in reach: bytes that cannot match)
                     if (reach) B4 = ld4(in + cand);
                     flush_ps();                       // (the previous sequence's store: behind this batch's gather)
-                    const bool valid = reach && (uint32_t)A0 == B4;            // :204-206 (m >= 4)
-                    W = first_lane(__ballot(valid));
+                    W = first_lane(__builtin_amdgcn_uicmp(B4, (uint32_t)A0, 32 /* eq */));      // :204-206 (m >= 4); the compare's mask itself
                     CPHASE(0);
                     {
                         // commit: the lanes up to the winner, or all below the cut, write their position; the others restore their
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     const bool bwd = lane >= 32u, okb = li < maxbt;
                     const uint32_t oa = bwd ? (okb ? 0u - 1u - li : 0u) : 4u + li;          // (a backward lane beyond the bound reads a harmless byte)
                     const uint32_t xa = in[m_pos + oa], xb = in[m_cand + oa];
-                    const unsigned long long mk = __ballot(xa != xb || (bwd && !okb));
+                    const unsigned long long mk = __builtin_amdgcn_uicmp(xa, xb, 33 /* ne */) | (0xFFFFFFFF00000000ull & ~__builtin_amdgcn_uicmp(li, maxbt, 36 /* ult */));
                     const uint32_t mlo = (uint32_t)mk, mhi = (uint32_t)(mk >> 32);
                     const uint32_t wm = mlo ? 4u + (uint32_t)__builtin_ctz(mlo) : 36u, wbt = mhi ? (uint32_t)__builtin_ctz(mhi) : 32u;
                     // table.replace(input, cursor - 2) (:218): the 8 bytes at cursor - 2 are the probe bytes of lane W + m - 2, whose
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     bool have_me = !more_m;
                     if (more_m) {
                         const uint64_t x = ld8(in + m_pos + 36u + lane * 8u) ^ ld8(in + m_cand + 36u + lane * 8u);
-                        const unsigned long long neq = __ballot(x != 0ull);
+                        const unsigned long long neq = __builtin_amdgcn_ballot_w64(x != 0ull);
                         if (neq) {
                             const uint32_t fl = (uint32_t)__builtin_ctzll(neq);
                             const uint32_t xlo = __builtin_amdgcn_readlane((uint32_t)x, fl), xhi = __builtin_amdgcn_readlane((uint32_t)(x >> 32), fl);
@@ -419,9 +419,9 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 if (active) atomicMin(&tab32[wi], lane);
                 if (active) first = tab32[wi];
                 const bool conf = active && first != lane;                // an earlier lane touches the same word
-                const uint32_t D = first_lane(__ballot(conf));            // 64 = none; the batch is cut after lane D
-                const uint32_t e_end = easy ? 64u : first_lane(__ballot(endk));
-                const uint32_t x_end = easy ? 64u : first_lane(__ballot(epk));
+                const uint32_t D = first_lane(__builtin_amdgcn_ballot_w64(conf));            // 64 = none; the batch is cut after lane D
+                const uint32_t e_end = easy ? 64u : first_lane(__builtin_amdgcn_ballot_w64(endk));
+                const uint32_t x_end = easy ? 64u : first_lane(__builtin_amdgcn_ballot_w64(epk));
                 // lanes below D are alone in their word, so lane D's word holds exactly one earlier lane, fD: either the same
                 // slot (the collision the sequential algorithm would see) or the neighbouring slot (nothing to see)
                 uint32_t fD = 64u; bool true_dup = false;
@@ -466,7 +466,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                         bt_loc = xp ? (uint32_t)(__builtin_clzll(xp) >> 3) : 8u;
                     }
                 }
-                const uint32_t W = first_lane(__ballot(valid));
+                const uint32_t W = first_lane(__builtin_amdgcn_ballot_w64(valid));
                 // last lane whose `replace` really executed in sequential order (+1)
                 uint32_t commit_end;   // lanes [0, commit_end) commit
                 int outcome;           // 0 = continue, 1 = match at W, 2 = end of input
@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                 bool done = false;
                 while (!done && alen - m >= 512u) {              // 8 bytes per lane
                     const uint64_t x = ld8(a + m + lane * 8u) ^ ld8(b + m + lane * 8u);
-                    const unsigned long long neq = __ballot(x != 0ull);
+                    const unsigned long long neq = __builtin_amdgcn_ballot_w64(x != 0ull);
                     if (neq) {
                         const uint32_t fl = (uint32_t)__builtin_ctzll(neq);
                         const uint32_t xlo = __builtin_amdgcn_readlane((uint32_t)x, fl), xhi = __builtin_amdgcn_readlane((uint32_t)(x >> 32), fl);
@@ -563,7 +563,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     const bool inr = i < alen;
                     bool ne = true;
                     if (inr) ne = a[i] != b[i];
-                    const unsigned long long neq = __ballot(ne);   // out-of-range lanes stop the scan
+                    const unsigned long long neq = __builtin_amdgcn_ballot_w64(ne);   // out-of-range lanes stop the scan
                     if (neq) { m += (uint32_t)__builtin_ctzll(neq); done = true; }
                     else m += 64u;
                 }
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
                     const uint32_t i = bt + lane;
                     bool ne = true;
                     if (i < maxbt) ne = in[m_pos - 1u - i] != in[m_cand - 1u - i];
-                    const unsigned long long neq = __ballot(ne);
+                    const unsigned long long neq = __builtin_amdgcn_ballot_w64(ne);
                     if (neq) { bt += (uint32_t)__builtin_ctzll(neq); done = true; }
                     else bt += 64u;
                 }
