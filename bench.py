@@ -155,12 +155,12 @@ def traffic_for(kernel_name, which, n_jobs):
     committed under profiles/ (tools/refresh_profiles.sh), SCALED by job count from the pass's own (smaller) batch — the second
     value says from how many copies; (None, None) when the committed profile is of another kernel."""
     tj = path = None
-    for name in ("r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
+    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             tj = json.load(open(path)).get(which)
             break
-    if not tj or tj.get("kernel") != kernel_name:
+    if not tj or tj.get("kernel", "").split("<")[0] != kernel_name.split("<")[0].split(" +")[0]:
         return None, None
     return ((2 * tj["FETCH_SIZE_KB"] + tj["WRITE_SIZE_KB"]) * 1024.0 * n_jobs / tj["jobs"],
             {"kind": "scaled from a separate PMC pass", "scaled_from_copies": int(round(tj["jobs"] / (49.0 if which == "decompress" else 51.0))),
@@ -172,11 +172,19 @@ def last_decompress_launch(ffi):
     return ffi.lib().lzf_last_decompress_launch().decode()
 
 
-def issue_ceiling(copies, kernel_ms, achieved_gbs, cus=256):
+def issue_ceiling(copies, kernel_ms, achieved_gbs, cus=256, which="decompress"):
     ipseq, seq_per_copy, best_rate = 27.96, 11.71e6, 3.29            # wave-instructions per sequence; sequences per copy; instr / ns / CU (32 waves per CU)
+    kind = "model (constants from the r01 / r02 counter passes, not re-measured in this run; only kernel_ms is this run's)"
+    pc = os.path.join(ROOT, "profiles", "r05_issue_counters.json")
+    if os.path.exists(pc):                                            # round 5: the instruction counters re-measured with the round's kernels (tools/refresh_profiles.sh)
+        m = json.load(open(pc)).get(which)
+        if m:
+            ipseq = float(m["wave_instructions_per_sequence"])
+            kind = "wave-instructions per sequence from this round's PMC pass (profiles/r05_issue_counters.json: %s), kernel_ms from this run, best_rate from tools/issue_mix_microbench.hip (r01)" % (
+                ", ".join(f"{k[9:]} {v}" for k, v in sorted(m["per_sequence"].items()) if k.startswith("SQ_INSTS")))
     rate = ipseq * seq_per_copy * copies / (kernel_ms * 1e-3) / 1e9 / cus
     ceil_gbs = achieved_gbs * best_rate / rate
-    return {"kind": "model (constants from the r01 / r02 counter passes, not re-measured in this run; only kernel_ms is this run's)", "wave_instructions_per_sequence": ipseq, "retired_per_ns_per_cu": round(rate, 3), "best_measured_mix_per_ns_per_cu": best_rate,
+    return {"kind": kind, "wave_instructions_per_sequence": ipseq, "retired_per_ns_per_cu": round(rate, 3), "best_measured_mix_per_ns_per_cu": best_rate,
             "ceiling_gbs": round(ceil_gbs, 1), "ceiling_frac_of_hbm": round(ceil_gbs / HBM_PEAK_GBS, 4), "achieved_frac_of_ceiling": round(rate / best_rate, 3)}
 
 
@@ -202,7 +210,7 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
-def launch_check(args, rank, world):
+def launch_check(args, rank, world, emit):
     """The launcher path without a GPU: gloo group, every rank's block range of the config4 stream gathered, rank 0 prints them."""
     import torch
     import torch.distributed as dist
@@ -215,8 +223,7 @@ def launch_check(args, rank, world):
     dist.all_gather(allr, mine)
     dist.barrier()
     if rank == 0:
-        print(json.dumps({"launch_check": True, "world": dist.get_world_size(), "blocks": args.blocks,
-                          "ranges": [[int(x) for x in t.tolist()] for t in allr]}), flush=True)
+        emit({"launch_check": True, "world": dist.get_world_size(), "blocks": args.blocks, "ranges": [[int(x) for x in t.tolist()] for t in allr]})
     dist.destroy_process_group()
     return 0
 
@@ -244,13 +251,22 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under a launcher: become one (the ranks inherit stdout: rank 0's JSON line is this process's output)
         sys.exit(self_launch(args.gpus))
+    # stdout carries ONE JSON line and nothing else: libraries that write to the C-level stdout (RCCL prints a version banner when a
+    # communicator is made) are sent to stderr; the line goes to the real stdout through its saved descriptor
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(obj):
+        os.write(real_stdout, (json.dumps(obj) + "\n").encode())
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if args.launch_check:
-        return launch_check(args, rank, world)
+        return launch_check(args, rank, world, emit)
 
     t0 = time.time()
     bases = None
@@ -300,7 +316,7 @@ def main():
             if rank == 0:
                 line["config5"] = {k: l5[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "roofline", "compress", "u16_raw")}
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line)
     if dist:
         dist.destroy_process_group()
 
@@ -444,7 +460,7 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
     d_bytes = float(lens[kidx].sum() + clen[kidx].sum())               # C + N of the kernel's jobs
     kname = kname_main
     d_traffic, d_traffic_info = traffic_for(kname, "decompress", nk)
-    c_traffic, c_traffic_info = traffic_for("lzf_compress_compact_kernel<false>", "compress", nblk)
+    c_traffic, c_traffic_info = traffic_for(c_launch, "compress", nblk)
     d_achieved = d_bytes / (d_kernel_ms * 1e-3) / 1e9
     c_achieved = c_bytes / (c_kernel_ms * 1e-3) / 1e9
 
@@ -518,7 +534,8 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
                      "roofline": {"bound": "hbm", "kernel": c_launch,
                                   "achieved": round(c_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(c_achieved / HBM_PEAK_GBS, 5), "traffic": c_traffic, "traffic_provenance": c_traffic_info,
-                                  "algorithmic_bytes_per_launch": c_bytes, "kernel_ms": round(c_kernel_ms, 3)}},
+                                  "algorithmic_bytes_per_launch": c_bytes, "kernel_ms": round(c_kernel_ms, 3),
+                                  "issue_ceiling": issue_ceiling(copies, c_kernel_ms, c_achieved, which="compress")}},
         # the same call at smaller batch sizes (compressed blocks of the first 1 / 4 / 20 copies; kernel time by HIP events,
         # median of 5): up to 1024 blocks go through the segmented pipeline, a block decoded by many wavefronts
         "batch_sweep": sweep,
@@ -725,7 +742,7 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
                    "gather_ms": round(g_ms, 3), "gather_path": gather_path,
                    "n_ranks_seen_by_rccl": n_seen, "content_checksum": xx},
         "roofline": {"bound": "hbm", "kernel": state["launch"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_for("lzf_compress_compact_kernel<false>", "compress", nloc)[0],
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_for(state["launch"], "compress", nloc)[0],
                      "algorithmic_bytes_per_launch": alg, "kernel_ms": round(k_ms, 4)},
         "cpu_baseline": cpu,
     }
