@@ -15,6 +15,9 @@ if os.environ.get("LZF_ONLY_BLOCK"):     # analysis: tile one block of the corpu
 m = n * copies
 d_out = torch.empty(m * BS, dtype=torch.uint8, device='cuda')
 cj = np.tile(j1, copies)
+if os.environ.get("LZF_DISTINCT_BUFFERS"):      # every copy reads its own bytes (same content): separates cache locality from data effects
+    d_all = d_in.repeat(copies)
+    cj['input'] = (d_all.data_ptr() + (np.repeat(np.arange(copies, dtype=np.uint64), n) * np.uint64(len(data)))) + (cj['input'] - np.uint64(d_in.data_ptr()))
 if os.environ.get("LZF_ORDER"):      # analysis: jobs ordered by a per-block cost list (one number per line), longest first
     cost = np.tile(np.loadtxt(os.environ["LZF_ORDER"]), copies)
     cj = cj[np.argsort(-cost, kind="stable")]
