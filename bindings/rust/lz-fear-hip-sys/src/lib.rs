@@ -122,3 +122,21 @@ extern "C" {
     pub fn lzf_frame_set_host_threads(n: u32);
     pub fn lzf_frame_set_memory_budget(bytes: usize);
 }
+
+// lzfear_dist.h (liblzfear_dist.so; links librccl): the one exchange of the block-sharded frame — what a multi-GPU `src/framed` calls behind
+// its per-rank lzf_compress_batch (src/framed/compress.rs:243-258 for blocks compressed on different GPUs).  UNVERIFIED source, like the rest of
+// this crate: there is no Rust toolchain in the build image.
+#[repr(C)] pub struct lzf_dist_comm { _private: [u8; 0] }
+pub const LZF_DIST_UNIQUE_ID_BYTES: usize = 128;
+#[link(name = "lzfear_dist")]
+extern "C" {
+    pub fn lzf_dist_unique_id(id: *mut u8) -> c_int;
+    pub fn lzf_dist_comm_init(id: *const u8, rank: c_int, world: c_int, comm: *mut *mut lzf_dist_comm) -> c_int;
+    pub fn lzf_dist_comm_count(comm: *const lzf_dist_comm) -> c_int;
+    pub fn lzf_dist_comm_free(comm: *mut lzf_dist_comm);
+    pub fn lzf_frame_gather(comm: *mut lzf_dist_comm, d_results: *const lzf_job_result, d_comp: *const u8, d_src: *const u8,
+                            stride: u64, block_size: u64, n_local: u32, n_blocks: u32, last_block_len: u64,
+                            header: *const u8, header_len: u32, d_frame: *mut u8, frame_cap: u64,
+                            frame_len: *mut u64, comp_total: *mut u64, hip_stream: *mut c_void) -> c_int;
+    pub fn lzf_dist_last_error() -> *const c_char;
+}
