@@ -382,6 +382,10 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
     assert np.all(ok | full), f"compress statuses: {np.unique(cres['status'])}"
     clen = np.where(ok, cres["out_len"], 0).astype(np.uint64)
     c_kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in c_evs]))
+    # how evenly the launch fills the chip: the jobs' own wave times (results[].reserved, kilo-cycles) against slots x duration
+    c_kc = cres["reserved"].astype(np.float64) * 1024.0
+    c_fill = {"sum_of_wave_gcycles": round(float(c_kc.sum()) / 1e9, 2), "longest_job_mcycles": round(float(c_kc.max()) / 1e6, 1),
+              "mean_job_mcycles": round(float(c_kc.mean()) / 1e6, 1)}
     c_bytes = float(lens.sum() + clen.sum())                           # N + C
 
     # stored blocks (incompressible, framed/compress.rs:250-255): the frame carries the raw bytes
@@ -535,7 +539,8 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
                                   "achieved": round(c_achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                   "frac": round(c_achieved / HBM_PEAK_GBS, 5), "traffic": c_traffic, "traffic_provenance": c_traffic_info,
                                   "algorithmic_bytes_per_launch": c_bytes, "kernel_ms": round(c_kernel_ms, 3),
-                                  "issue_ceiling": issue_ceiling(copies, c_kernel_ms, c_achieved, which="compress")}},
+                                  "issue_ceiling": issue_ceiling(copies, c_kernel_ms, c_achieved, which="compress")},
+                     "launch_fill": c_fill},
         # the same call at smaller batch sizes (compressed blocks of the first 1 / 4 / 20 copies; kernel time by HIP events,
         # median of 5): up to 1024 blocks go through the segmented pipeline, a block decoded by many wavefronts
         "batch_sweep": sweep,

@@ -118,6 +118,18 @@ struct SimtGpu {
         asm volatile("s_mov_b64 exec, 1\n\tds_write_b128 %0, %1\n\tds_write_b64 %2, %3\n\ts_mov_b64 exec, -1"
                      ::"v"(lds_a + desc_byte), "v"(d), "v"(lds_a + flag_byte), "v"(((uint64_t)f1 << 32) | f0) : "memory");
     }
+    // compare masks as scalars (v_cmp writes the lane mask directly; a ballot of a bool goes through a vector register and back), the first
+    // set lane of a mask bounded from above in two scalar instructions (s_ff1 gives 0xFFFFFFFF for an empty mask), and a predicated
+    // 4-byte read at any alignment that leaves the other lanes' value alone
+    LZF_SIMT_FN unsigned long long mask_ne(uint32_t a, uint32_t c) const { return __builtin_amdgcn_uicmp(a, c, 33); }
+    LZF_SIMT_FN unsigned long long mask_eq(uint32_t a, uint32_t c) const { return __builtin_amdgcn_uicmp(a, c, 32); }
+    LZF_SIMT_FN unsigned long long mask_lt(uint32_t a, uint32_t c) const { return __builtin_amdgcn_uicmp(a, c, 36); }
+    LZF_SIMT_FN uint32_t first_lane_min(unsigned long long m, uint32_t bound) const {
+        uint32_t r; asm("s_ff1_i32_b64 %0, %1\n\ts_min_u32 %0, %0, %2" : "=s"(r) : "s"(m), "s"(bound)); return r;
+    }
+    LZF_SIMT_FN uint32_t lds_rd32b_keep(bool p, uint32_t byte, uint32_t keep) const {
+        uint32_t r = keep; if (p) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "+v"(r) : "v"(lds_a + byte) : "memory"); return r;
+    }
     LZF_SIMT_FN void sleep() const { __builtin_amdgcn_s_sleep(2); }
     LZF_SIMT_FN void barrier() const { __syncthreads(); }
     LZF_SIMT_FN void lds_fence() const { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
@@ -248,6 +260,11 @@ struct SimtEmu {
     void push16_flag2(uint32_t desc_byte, u32x4 d, uint32_t flag_byte, uint32_t f0, uint32_t f1) const {
         sync(); if (my == 0u) { memcpy((uint8_t*)w->L + desc_byte, &d, 16); w->L[flag_byte >> 2] = f0; w->L[(flag_byte >> 2) + 1u] = f1; }
     }
+    unsigned long long mask_ne(uint32_t a, uint32_t c) const { return ballot(a != c); }
+    unsigned long long mask_eq(uint32_t a, uint32_t c) const { return ballot(a == c); }
+    unsigned long long mask_lt(uint32_t a, uint32_t c) const { return ballot(a < c); }
+    uint32_t first_lane_min(unsigned long long m, uint32_t bound) const { const uint32_t f = m ? simt_ctz64(m) : 0xFFFFFFFFu; return f < bound ? f : bound; }
+    uint32_t lds_rd32b_keep(bool p, uint32_t byte, uint32_t keep) const { sync(); uint32_t v = keep; if (p) memcpy(&v, (const uint8_t*)w->L + byte, 4); return v; }
     void sleep() const { sync(); }
     void lds_fence() const {}
     // all waves of the workgroup: the lanes of a wave test the counter at the same lock-step point (other waves only run between
