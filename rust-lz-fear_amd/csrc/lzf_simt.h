@@ -127,6 +127,7 @@ struct SimtGpu {
     LZF_SIMT_FN uint32_t first_lane_min(unsigned long long m, uint32_t bound) const {
         uint32_t r; asm("s_ff1_i32_b64 %0, %1\n\ts_min_u32 %0, %0, %2" : "=s"(r) : "s"(m), "s"(bound)); return r;
     }
+    LZF_SIMT_FN uint32_t ff1_32(uint32_t m) const { uint32_t r; asm("s_ff1_i32_b32 %0, %1" : "=s"(r) : "s"(m)); return r; }      // 0xFFFFFFFF for 0
     LZF_SIMT_FN uint32_t lds_rd32b_keep(bool p, uint32_t byte, uint32_t keep) const {
         uint32_t r = keep; if (p) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "+v"(r) : "v"(lds_a + byte) : "memory"); return r;
     }
@@ -264,6 +265,7 @@ struct SimtEmu {
     unsigned long long mask_eq(uint32_t a, uint32_t c) const { return ballot(a == c); }
     unsigned long long mask_lt(uint32_t a, uint32_t c) const { return ballot(a < c); }
     uint32_t first_lane_min(unsigned long long m, uint32_t bound) const { const uint32_t f = m ? simt_ctz64(m) : 0xFFFFFFFFu; return f < bound ? f : bound; }
+    uint32_t ff1_32(uint32_t m) const { return m ? simt_ctz32(m) : 0xFFFFFFFFu; }
     uint32_t lds_rd32b_keep(bool p, uint32_t byte, uint32_t keep) const { sync(); uint32_t v = keep; if (p) memcpy(&v, (const uint8_t*)w->L + byte, 4); return v; }
     void sleep() const { sync(); }
     void lds_fence() const {}

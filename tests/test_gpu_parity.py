@@ -195,9 +195,9 @@ def test_every_compress_kernel(kernel):
 
 
 def test_product_dispatch_every_batch_size_class():
-    """The product library has no knobs: the batch size alone picks the kernel (paired48 up to 8 blocks per CU, paired24
-    up to 64 per CU, staged16 beyond) and the launch order (longest first beyond 8 blocks per CU for decompress, beyond
-    18 per CU for compress).  Batches on both sides of every threshold, small blocks so the oracle keeps up."""
+    """The product library has no knobs: the batch size alone picks the kernel (decompress: paired48 up to 8 blocks per CU, paired24
+    up to 64 per CU, staged16 beyond; compress: the team kernel up to one block per CU, the compact kernel beyond) and the launch
+    order (longest first beyond 8 blocks per CU for decompress, beyond 18 per CU for compress).  Batches on both sides of every threshold, small blocks so the oracle keeps up."""
     rng = np.random.default_rng(5)
     base = synth.silesia_mix(0, 1 << 20)
     def blocks(n):
@@ -206,9 +206,14 @@ def test_product_dispatch_every_batch_size_class():
             a = int(rng.integers(0, (1 << 20) - 3000)); ln = int(rng.integers(1, 2500))
             out.append(base[a:a + ln].tobytes())
         return out
-    for n in (300, 2100, 4700, 16500):
+    import torch
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    for n in (cus - 6, cus, cus + 44, 2100, 4700, 16500):
         bl = blocks(n)
         comp = gpu_compress([dict(input=b, out_cap=len(b) + len(b) // 200 + 32) for b in bl])
+        # the compressor's latency class: no more jobs than compute units -> a team of wavefronts and a CU's LDS per block
+        launch = ffi.lib().lzf_last_compress_launch().decode()
+        assert launch.startswith("lzf_compress_team_kernel" if n <= cus else "lzf_compress_compact_kernel"), (n, launch)
         step = max(1, n // 400)
         for b, (rc, c) in list(zip(bl, comp))[::step]:
             erc, ec = o.compress2(b, cap=len(b) + len(b) // 200 + 32)
