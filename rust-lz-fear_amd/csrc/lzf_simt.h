@@ -125,8 +125,18 @@ struct SimtGpu {
     LZF_SIMT_FN unsigned long long mask_eq(uint32_t a, uint32_t c) const { return __builtin_amdgcn_uicmp(a, c, 32); }
     LZF_SIMT_FN unsigned long long mask_lt(uint32_t a, uint32_t c) const { return __builtin_amdgcn_uicmp(a, c, 36); }
     LZF_SIMT_FN uint32_t first_lane_min(unsigned long long m, uint32_t bound) const {
-        uint32_t r; asm("s_ff1_i32_b64 %0, %1\n\ts_min_u32 %0, %0, %2" : "=s"(r) : "s"(m), "s"(bound)); return r;
+        uint32_t r; asm("s_ff1_i32_b64 %0, %1\n\ts_min_u32 %0, %0, %2" : "=s"(r) : "s"(m), "s"(bound) : "scc"); return r;
     }
+    // per-lane select by a UNIFORM lane mask (an SGPR pair built by scalar instructions): a scalar result feeding a vector instruction costs
+    // nothing, a vector compare feeding a scalar one ~16 cycles on a lone wave (tools/lone_wave_microbench.hip) — bounds that are uniform are
+    // therefore turned into masks on the scalar side instead of being compared per lane
+    LZF_SIMT_FN uint32_t sel(unsigned long long m, uint32_t if1, uint32_t if0) const {
+        uint32_t r; asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(if0), "v"(if1), "s"(m)); return r;
+    }
+    LZF_SIMT_FN uint32_t lds_rd32bu(uint32_t byte) const {
+        uint32_t r; asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(r) : "v"(lds_a + byte) : "memory"); return r;
+    }
+    LZF_SIMT_FN uint32_t smin(uint32_t a, uint32_t c) const { uint32_t r; asm("s_min_u32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(c) : "scc"); return r; }      // (uniform operands: stays on the scalar side)
     LZF_SIMT_FN uint32_t ff1_32(uint32_t m) const { uint32_t r; asm("s_ff1_i32_b32 %0, %1" : "=s"(r) : "s"(m)); return r; }      // 0xFFFFFFFF for 0
     LZF_SIMT_FN uint32_t lds_rd32b_keep(bool p, uint32_t byte, uint32_t keep) const {
         uint32_t r = keep; if (p) asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "+v"(r) : "v"(lds_a + byte) : "memory"); return r;
@@ -265,6 +275,9 @@ struct SimtEmu {
     unsigned long long mask_eq(uint32_t a, uint32_t c) const { return ballot(a == c); }
     unsigned long long mask_lt(uint32_t a, uint32_t c) const { return ballot(a < c); }
     uint32_t first_lane_min(unsigned long long m, uint32_t bound) const { const uint32_t f = m ? simt_ctz64(m) : 0xFFFFFFFFu; return f < bound ? f : bound; }
+    uint32_t sel(unsigned long long m, uint32_t if1, uint32_t if0) const { return ((m >> my) & 1ull) ? if1 : if0; }
+    uint32_t lds_rd32bu(uint32_t byte) const { sync(); uint32_t v; memcpy(&v, (const uint8_t*)w->L + byte, 4); return v; }
+    uint32_t smin(uint32_t a, uint32_t c) const { return a < c ? a : c; }
     uint32_t ff1_32(uint32_t m) const { return m ? simt_ctz32(m) : 0xFFFFFFFFu; }
     uint32_t lds_rd32b_keep(bool p, uint32_t byte, uint32_t keep) const { sync(); uint32_t v = keep; if (p) memcpy(&v, (const uint8_t*)w->L + byte, 4); return v; }
     void sleep() const { sync(); }
