@@ -110,6 +110,33 @@ __global__ void k(uint64_t* out, uint32_t seed, uint32_t which) {
       t0 = __builtin_readcyclecounter();
       for (int it = 0; it < 64; ++it) { asm volatile(REP16("s_add_u32 %1, %1, 1\n\tv_add_u32 %0, %1, %0\n\tv_readfirstlane_b32 %1, %0\n\t") : "+v"(v), "+s"(sl) :: "scc"); }
       t1 = __builtin_readcyclecounter(); if (lane == 0) out[19] = t1 - t0; v ^= sl; }
+    if (which >> 20 & 1u) {       // taken branches
+      t0 = __builtin_readcyclecounter();
+      for (int it = 0; it < 64; ++it) { asm volatile(REP16("s_branch 1f\n\ts_nop 0\n1:\n\ts_branch 2f\n\ts_nop 0\n2:\n\ts_branch 3f\n\ts_nop 0\n3:\n\ts_branch 4f\n\ts_nop 0\n4:\n\t")); }
+      t1 = __builtin_readcyclecounter(); if (lane == 0) out[20] = t1 - t0; }
+    if (which >> 21 & 1u) {       // conditional branches not taken
+      t0 = __builtin_readcyclecounter();
+      for (int it = 0; it < 64; ++it) { asm volatile("s_cmp_eq_u32 0, 1\n\t" REP64("s_cbranch_scc1 9f\n\t") "9:\n\t" ::: "scc"); }
+      t1 = __builtin_readcyclecounter(); if (lane == 0) out[21] = t1 - t0; }
+    if (which >> 22 & 1u) {       // dependent v_mad_u64_u32
+      uint64_t acc = v;
+      t0 = __builtin_readcyclecounter();
+      for (int it = 0; it < 64; ++it) {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) { asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, 0" : "=v"(acc) : "v"((uint32_t)acc), "s"(0x1BBCDCBBu) : "vcc"); }
+      }
+      t1 = __builtin_readcyclecounter(); if (lane == 0) out[22] = t1 - t0; v ^= (uint32_t)acc; }
+    if (which >> 23 & 1u) {       // ds_write_b32 issue, no wait in between (64 lanes, own words)
+      t0 = __builtin_readcyclecounter();
+      for (int it = 0; it < 64; ++it) { asm volatile(REP16("ds_write_b32 %0, %1\n\t") "s_waitcnt lgkmcnt(0)" :: "v"(lane * 4u), "v"(v) : "memory"); }
+      t1 = __builtin_readcyclecounter(); if (lane == 0) out[23] = t1 - t0; }
+    if (which >> 24 & 1u) {       // the descriptor push: EXEC to lane 0, ds_write_b128 + ds_write_b64, EXEC back (no wait)
+      typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+      u4 d = {v, v, v, v}; uint64_t fl = v;
+      t0 = __builtin_readcyclecounter();
+      for (int it = 0; it < 64; ++it) { asm volatile(REP16("s_mov_b64 exec, 1\n\tds_write_b128 %0, %1\n\tds_write_b64 %0, %2 offset:64\n\ts_mov_b64 exec, -1\n\t") :: "v"(lane * 16u), "v"(d), "v"(fl) : "memory"); }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      t1 = __builtin_readcyclecounter(); if (lane == 0) out[24] = t1 - t0; }
     if (lane == 0) out[31] = v + a;
 }
 int main(int argc, char** argv) {
@@ -122,9 +149,10 @@ int main(int argc, char** argv) {
                            "tag protocol: 4 DS + wait + restore + shift (16 slots)", "2 x ds_read_u8 + misaligned ds_read_b64, one wait + 3 VALU",
                            "v_cmp -> vcc -> s_ff1 -> v_add (3 instr)", "v_readlane -> s_nop 1 -> v_add (3)", "v_readfirstlane -> s_add -> v_add (3)", "s_nop 3",
                            "v_cmp -> s_nop 1 -> v_cndmask vcc -> v_add (4)", "s_add -> v_add -> v_add (3)", "v_cmp -> s_and_saveexec -> v_add -> s_mov exec (4)",
-                           "s_and -> v_readlane (lane select from the SALU) -> s_add (3)", "s_and -> v_readlane (constant lane) -> s_add (3)", "v_cmp -> s_ff1 -> s_min (3)", "s_add -> v_add -> v_readfirstlane (3)"};
-    const double per[] = {4096, 4096, 4096, 1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024, 4096, 1024, 1024, 1024, 1024, 1024, 1024, 1024};
+                           "s_and -> v_readlane (lane select from the SALU) -> s_add (3)", "s_and -> v_readlane (constant lane) -> s_add (3)", "v_cmp -> s_ff1 -> s_min (3)", "s_add -> v_add -> v_readfirstlane (3)",
+                           "taken s_branch (over one s_nop)", "s_cbranch_scc1 not taken", "dependent v_mad_u64_u32", "ds_write_b32 x16, one wait", "push: exec=1, ds_write_b128, ds_write_b64, exec=-1"};
+    const double per[] = {4096, 4096, 4096, 1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024, 1024, 4096, 1024, 1024, 1024, 1024, 1024, 1024, 1024, 4096, 4096, 1024, 1024, 1024};
     printf("one wavefront alone on a CU, gfx950; __builtin_readcyclecounter() ticks per unit\n");
-    for (int i = 0; i < 20; ++i) if (mask >> i & 1u) printf("%-60s %8.1f ticks per %s\n", names[i], (double)h[i] / per[i], (i < 3 || i == 12) ? "instruction" : "group");
+    for (int i = 0; i < 25; ++i) if (mask >> i & 1u) printf("%-60s %8.1f ticks per %s\n", names[i], (double)h[i] / per[i], (i < 3 || i == 12 || i == 20 || i == 21 || i == 22) ? "instruction" : "group");
     return 0;
 }
