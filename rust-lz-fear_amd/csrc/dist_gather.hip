@@ -171,13 +171,16 @@ int lzf_frame_gather(lzf_dist_comm* comm, const lzf_job_result* d_results, const
     // ---- exchange: my segment to every peer, theirs into their places (one grouped operation)
     if (world > 1) {
         NCCLOK(ncclGroupStart());
-        for (int p = 0; p < world; ++p) {
+        ncclResult_t gr = ncclSuccess;                                   // (a failed call inside the group still closes it)
+        for (int p = 0; p < world && gr == ncclSuccess; ++p) {
             if (p == rank) continue;
             const uint64_t mine = seg_off[(size_t)rank + 1u] - seg_off[rank], theirs = seg_off[(size_t)p + 1u] - seg_off[p];
-            if (mine) NCCLOK(ncclSend(d_frame + seg_off[rank], mine, ncclUint8, p, comm->comm, st));
-            if (theirs) NCCLOK(ncclRecv(d_frame + seg_off[p], theirs, ncclUint8, p, comm->comm, st));
+            if (mine) gr = ncclSend(d_frame + seg_off[rank], mine, ncclUint8, p, comm->comm, st);
+            if (theirs && gr == ncclSuccess) gr = ncclRecv(d_frame + seg_off[p], theirs, ncclUint8, p, comm->comm, st);
         }
-        NCCLOK(ncclGroupEnd());
+        const ncclResult_t ge = ncclGroupEnd();
+        if (gr != ncclSuccess) return fail(LZF_E_HIP, "ncclSend / ncclRecv", ncclGetErrorString(gr));
+        if (ge != ncclSuccess) return fail(LZF_E_HIP, "ncclGroupEnd", ncclGetErrorString(ge));
     }
     HIPOK(hipMemcpyAsync(d_frame, header, header_len, hipMemcpyHostToDevice, st));
     HIPOK(hipMemsetAsync(d_frame + flen - 4u, 0, 4u, st));           // EndMark (compress.rs:277)

@@ -125,7 +125,7 @@ struct SimtGpu {
     LZF_SIMT_FN unsigned long long mask_eq(uint32_t a, uint32_t c) const { return __builtin_amdgcn_uicmp(a, c, 32); }
     LZF_SIMT_FN unsigned long long mask_lt(uint32_t a, uint32_t c) const { return __builtin_amdgcn_uicmp(a, c, 36); }
     LZF_SIMT_FN uint32_t first_lane_min(unsigned long long m, uint32_t bound) const {
-        uint32_t r; asm("s_ff1_i32_b64 %0, %1\n\ts_min_u32 %0, %0, %2" : "=s"(r) : "s"(m), "s"(bound) : "scc"); return r;
+        uint32_t r; asm("s_ff1_i32_b64 %0, %1\n\ts_min_u32 %0, %0, %2" : "=&s"(r) : "s"(m), "s"(bound) : "scc"); return r;      // (early clobber: r must not share bound's register)
     }
     // per-lane select by a UNIFORM lane mask (an SGPR pair built by scalar instructions): a scalar result feeding a vector instruction costs
     // nothing, a vector compare feeding a scalar one ~16 cycles on a lone wave (tools/lone_wave_microbench.hip) — bounds that are uniform are
