@@ -127,6 +127,7 @@ struct SegScratch {
     void* base = nullptr;
     lzf::seg_ctx ctx{};
     size_t bytes = 0;
+    uint32_t* est = nullptr;       // [n] grouped calls: the jobs by sequences, most first (lzf_seg_rank_kernel)
 };
 inline uint32_t seg_nch_host(uint32_t len) { return len <= lzf::kSegChunk ? 1u : 1u + (len - lzf::kSegChunk + lzf::kSegStride - 1u) / lzf::kSegStride; }
 
@@ -164,6 +165,7 @@ bool seg_alloc(SegScratch& s, const lzf_decompress_job* d_jobs, lzf_job_result* 
     const size_t o_recs = take(sizeof(lzf::u32x4) * (size_t)c.rec_cap);
     const size_t o_ord = take(sizeof(uint32_t) * (size_t)n);
     const size_t o_len = take(sizeof(uint32_t) * (size_t)n);
+    const size_t o_est = take(sizeof(uint32_t) * (size_t)n);
     if (hipMallocAsync(&s.base, off, st) != hipSuccess) { (void)hipGetLastError(); s.base = nullptr; return false; }
     s.bytes = off;
     uint8_t* b = static_cast<uint8_t*>(s.base);
@@ -179,34 +181,153 @@ bool seg_alloc(SegScratch& s, const lzf_decompress_job* d_jobs, lzf_job_result* 
     c.order = (n > c.n_cu && n <= seg_max_jobs()) ? reinterpret_cast<uint32_t*>(b + o_ord) : nullptr;      // (one block per CU: nothing to balance)
     c.by_len = (n >= (c.n_cu + 7u) / 8u && n <= seg_max_jobs()) ? reinterpret_cast<uint32_t*>(b + o_len) : nullptr;       // (MI355X: 32 jobs and more)
     c.rec_by_len = n >= (c.n_cu + 3u) / 4u ? 1u : 0u;                                                                      // (64 and more)
+    c.g_off = 0u; c.g_n = n; c.grouped = 0u; c.res_prio = 0u;
+    s.est = reinterpret_cast<uint32_t*>(b + o_est);
     return true;
 }
 inline uint32_t seg_grid(uint32_t target, uint32_t n, uint32_t cap) {
     uint32_t g = target / n; if (g < 1u) g = 1u; if (g > cap) g = cap; return g;
 }
 // stages: 1 plan, 2 parse, 3 seam, 4 tilesum, 5 scan, 6 records (+ levels), 8 resolve (all when upto >= 8)
-int seg_launch(const lzf::seg_ctx& c, uint32_t upto, hipStream_t st) {
-    const uint32_t n = c.n_jobs;
+// seg_launch_prep: the stages that look at every job of the call; seg_launch_front: the chunk / tile stages of the group the context
+// names (ranks g_off .. g_off + g_n); seg_launch_resolve: its resolve stage.
+int seg_launch_prep(const lzf::seg_ctx& c, hipStream_t st) {
+    if (c.by_len && !c.grouped) LAUNCH(lzf::lzf_seg_by_len_kernel, dim3(1), dim3(1024), 0, st, c);
+    LAUNCH(lzf::lzf_seg_plan_kernel, dim3((c.n_jobs + 255u) / 256u), dim3(256), 0, st, c);
+    return LZF_OK;
+}
+int seg_launch_front(const lzf::seg_ctx& c, uint32_t upto, hipStream_t st) {
+    const uint32_t n = c.g_n;
     // workgroups per launch of the chunk / tile kernels: about one chunk and a handful of tiles each — with 8 192 / 32 768 (each
     // workgroup looping over a dozen chunks) the launches ended on their slowest loops: parse 4.3 -> 3.3 ms at 980 blocks, 1.02 -> 0.83 at 196
     uint32_t tg_parse = 1024u * c.n_cu, tg_tile = 2048u * c.n_cu;             // (MI355X: 262 144 and 524 288)
 #ifdef LZF_ANALYSIS      // LZF_SEG_GRID="parse,tiles": workgroups per launch of the chunk / tile kernels (A/B of the grid sizes)
     { static const char* e = getenv("LZF_SEG_GRID"); if (e) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a && b) { tg_parse = a; tg_tile = b; } } }
 #endif
-    if (c.by_len) LAUNCH(lzf::lzf_seg_by_len_kernel, dim3(1), dim3(1024), 0, st, c);
-    LAUNCH(lzf::lzf_seg_plan_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, c);
     if (upto >= 2) LAUNCH(lzf::lzf_seg_parse_kernel, dim3(seg_grid(tg_parse, n, c.maxch), n), dim3(64), 0, st, c);
     if (upto >= 3) LAUNCH(lzf::lzf_seg_seam_kernel, dim3(n), dim3(64), 0, st, c);
     if (upto >= 4) LAUNCH(lzf::lzf_seg_tilesum_kernel, dim3(seg_grid(tg_tile, n, c.maxtile), n), dim3(64), 0, st, c);
     if (upto >= 5) LAUNCH(lzf::lzf_seg_scan_kernel, dim3(n), dim3(64), 0, st, c);
     if (upto >= 6 && c.order) LAUNCH(lzf::lzf_seg_order_kernel, dim3(1), dim3(1024), 0, st, c);
     if (upto >= 6) LAUNCH(lzf::lzf_seg_records_kernel, dim3(seg_grid(tg_tile, n, c.maxtile), n), dim3(64), 0, st, c);
-    if (upto >= 8) {
-        if (c.ring_bytes == 131072u) LAUNCH(lzf::lzf_seg_resolve_pair_kernel<131072>, dim3(n), dim3(128), 0, st, c);
-        else if (c.ring_bytes == 65536u) LAUNCH(lzf::lzf_seg_resolve_pair_kernel<65536>, dim3(n), dim3(128), 0, st, c);
-        else LAUNCH(lzf::lzf_seg_resolve_pair_kernel<32768>, dim3(n), dim3(128), 0, st, c);
-    }
     return LZF_OK;
+}
+// the records stage (and the resolve stage's workgroup order) of the group the context names, on their own
+int seg_launch_records(const lzf::seg_ctx& c, hipStream_t st) {
+    const uint32_t n = c.g_n;
+    uint32_t tg_tile = 2048u * c.n_cu;
+#ifdef LZF_ANALYSIS
+    { static const char* e = getenv("LZF_SEG_GRID"); if (e) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a && b) tg_tile = b; } }
+#endif
+    uint32_t pad = 0;
+#ifdef LZF_ANALYSIS      // LZF_SEG_REC_PAD = bytes of unused LDS per workgroup of a grouped call's records stage (fewer of them resident under the resolve stages: A/B)
+    { static const uint32_t e = [] { const char* v = getenv("LZF_SEG_REC_PAD"); return v ? (uint32_t)atol(v) : 0u; }(); pad = e; }
+#endif
+    if (c.order) LAUNCH(lzf::lzf_seg_order_kernel, dim3(1), dim3(1024), 0, st, c);
+    LAUNCH(lzf::lzf_seg_records_kernel, dim3(seg_grid(tg_tile, n, c.maxtile), n), dim3(64), pad, st, c);
+    return LZF_OK;
+}
+int seg_launch_resolve(const lzf::seg_ctx& c, hipStream_t st) {
+    const uint32_t n = c.g_n;
+    if (c.ring_bytes == 131072u) LAUNCH(lzf::lzf_seg_resolve_pair_kernel<131072>, dim3(n), dim3(128), 0, st, c);
+    else if (c.ring_bytes == 65536u) LAUNCH(lzf::lzf_seg_resolve_pair_kernel<65536>, dim3(n), dim3(128), 0, st, c);
+    else LAUNCH(lzf::lzf_seg_resolve_pair_kernel<32768>, dim3(n), dim3(128), 0, st, c);
+    return LZF_OK;
+}
+int seg_launch(const lzf::seg_ctx& c, uint32_t upto, hipStream_t st) {
+    int rc = seg_launch_prep(c, st);
+    if (rc == LZF_OK) rc = seg_launch_front(c, upto, st);
+    if (rc == LZF_OK && upto >= 8) rc = seg_launch_resolve(c, st);
+    return rc;
+}
+
+// ---- groups: the records stage of a group runs under the resolve stage of the groups before it -------------------------------
+// The resolve stage is a chain per block (one pair of wavefronts, 7 ms for a 4 MiB text block whatever the batch) and leaves most
+// of the chip idle; the stages before it are throughput kernels.  A call of several hundred blocks therefore takes its last two
+// stages in groups, by sequences (known once the tiles are counted: lzf_seg_rank_kernel), most first: the caller's stream
+// carries every group's records stage back to back, each group's resolve stage starts on a stream of its own as soon as its
+// records are written (an event), and the caller's stream waits for all of them before the pair kernel looks for jobs the
+// pipeline left.  The call then takes records(first group) + resolve(longest block) instead of records(all) + resolve(longest
+// block), as long as the later groups — the blocks with fewer sequences — are through their shorter resolve stages by then.
+constexpr uint32_t kSegMaxGroups = 4;      // (the caller's stream + three: HIP runs four hardware queues by default, a fifth stream would share one and wait)
+struct SegGroups { uint32_t n = 1; uint32_t size[kSegMaxGroups] = {}; };
+SegGroups seg_groups(uint32_t n_jobs) {
+    SegGroups g; g.size[0] = n_jobs;
+    const uint32_t ncu = cu_count();
+    uint32_t pct[kSegMaxGroups] = {100}; uint32_t k = 1;
+    if (n_jobs >= (ncu + 7u) / 8u) { pct[0] = pct[1] = pct[2] = pct[3] = 25; k = 4; }      // (MI355X: 32 jobs and more; measured 49 .. 980 blocks: quarters beat halves and thirds)
+#ifdef LZF_ANALYSIS      // LZF_SEG_GROUPS="a,b,c,...": per cent of the jobs per group (A/B of the grouping; "100" = one group)
+    { static const char* e = getenv("LZF_SEG_GROUPS");
+      if (e) { uint32_t v[kSegMaxGroups] = {}, got = 0, sum = 0; const char* q = e;
+               while (got < kSegMaxGroups && *q) { char* end = nullptr; const unsigned long x = strtoul(q, &end, 10); if (end == q) break; v[got++] = (uint32_t)x; sum += (uint32_t)x; q = *end == ',' ? end + 1 : end; if (*end != ',') break; }
+               if (got >= 1 && sum == 100u && v[0]) { for (uint32_t i = 0; i < kSegMaxGroups; ++i) pct[i] = v[i]; k = got; } } }
+#endif
+    if (k <= 1u || n_jobs < 2u * k) return g;
+    uint32_t left = n_jobs; g.n = 0;
+    for (uint32_t i = 0; i < k && left; ++i) {
+        uint32_t sz = i + 1u == k ? left : (uint32_t)((uint64_t)n_jobs * pct[i] / 100u);
+        if (sz > left) sz = left;
+        if (!sz) continue;
+        g.size[g.n++] = sz; left -= sz;
+    }
+    if (left && g.n) g.size[g.n - 1u] += left;
+    return g;
+}
+// the streams and events of grouped calls: made once, kept; calls enqueue under the mutex (the work itself overlaps freely)
+struct SegLanes {
+    std::mutex mu;
+    hipStream_t s[kSegMaxGroups - 1u] = {};
+    hipEvent_t front[kSegMaxGroups - 1u] = {}, done[kSegMaxGroups - 1u] = {};
+    bool ok = false;
+};
+SegLanes* seg_lanes() {
+    static SegLanes* lanes = [] {
+        SegLanes* L = new SegLanes();
+        bool ok = true;
+        for (uint32_t i = 0; i < kSegMaxGroups - 1u && ok; ++i)
+            ok = hipStreamCreateWithFlags(&L->s[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&L->front[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&L->done[i], hipEventDisableTiming) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+        L->ok = ok;
+        return L;
+    }();
+    return lanes->ok ? lanes : nullptr;
+}
+int seg_enqueue_groups(SegScratch& s, const SegGroups& g, SegLanes& L, hipStream_t st) {
+    lzf::seg_ctx c = s.ctx;
+    std::lock_guard<std::mutex> lk(L.mu);
+    int rc = seg_launch_prep(c, st);
+    if (rc == LZF_OK) rc = seg_launch_front(c, 5u, st);         // plan .. scan over the whole call
+    if (rc != LZF_OK) return rc;
+    LAUNCH(lzf::lzf_seg_rank_kernel, dim3(1), dim3(1024), 0, st, c, s.est);      // s.est: the jobs by sequences, most first
+    c.by_len = s.est; c.grouped = 1u; c.res_prio = 1u;
+#ifdef LZF_ANALYSIS      // LZF_SEG_PRIO=0: the resolve stage at the default issue priority (A/B)
+    { static const int pr = [] { const char* e = getenv("LZF_SEG_PRIO"); return e ? atoi(e) : 1; }(); c.res_prio = pr ? 1u : 0u; }
+#endif
+    uint32_t off = 0, forked = 0;
+    for (uint32_t k = 0; k < g.n && rc == LZF_OK; ++k) {
+        c.g_off = off; c.g_n = g.size[k]; off += g.size[k];
+        rc = seg_launch_records(c, st);
+        if (rc != LZF_OK) break;
+        if (k + 1u < g.n) {
+            if (hipEventRecord(L.front[k], st) != hipSuccess || hipStreamWaitEvent(L.s[k], L.front[k], 0) != hipSuccess) { (void)hipGetLastError(); rc = LZF_E_HIP; break; }
+            rc = seg_launch_resolve(c, L.s[k]);
+            ++forked;                                            // (whatever was enqueued on the lane is joined below)
+            if (hipEventRecord(L.done[k], L.s[k]) != hipSuccess) { (void)hipGetLastError(); --forked; if (rc == LZF_OK) rc = LZF_E_HIP; if (hipStreamSynchronize(L.s[k]) != hipSuccess) (void)hipGetLastError(); }
+        } else {
+            rc = seg_launch_resolve(c, st);                      // the last group: on the caller's stream
+        }
+    }
+    for (uint32_t k = 0; k < forked; ++k)
+        if (hipStreamWaitEvent(st, L.done[k], 0) != hipSuccess) { (void)hipGetLastError(); if (hipStreamSynchronize(L.s[k]) != hipSuccess) (void)hipGetLastError(); if (rc == LZF_OK) rc = LZF_E_HIP; }
+    return rc;
+}
+int seg_launch_grouped(SegScratch& s, const SegGroups& g, SegLanes& L, hipStream_t st) {
+    const int rc = seg_enqueue_groups(s, g, L, st);
+    if (rc != LZF_OK)                                            // (a launch failed part-way: nothing may still be running on a lane when the caller frees the scratch)
+        for (uint32_t k = 0; k < kSegMaxGroups - 1u; ++k) if (hipStreamSynchronize(L.s[k]) != hipSuccess) (void)hipGetLastError();
+    return rc;
 }
 // The whole call: pipeline, then the pair kernel over what the pipeline did not finish.
 int seg_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n, uint32_t min_in, hipStream_t st, bool* used, uint64_t max_in_hint, uint32_t* ring_used) {
@@ -215,7 +336,9 @@ int seg_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, 
     if (max_in_hint < min_in) return LZF_OK;                                      // (no job can be in the pipeline's window)
     if (!seg_alloc(s, d_jobs, d_results, n, min_in, st, max_in_hint)) return LZF_OK;      // (no scratch: the caller launches the pair kernel over everything)
     *used = true; *ring_used = s.ctx.ring_bytes;
-    int rc = seg_launch(s.ctx, 8u, st);
+    const SegGroups g = seg_groups(n);
+    SegLanes* lanes = g.n > 1u ? seg_lanes() : nullptr;
+    int rc = lanes ? seg_launch_grouped(s, g, *lanes, st) : seg_launch(s.ctx, 8u, st);
     if (rc == LZF_OK) {
         hipLaunchKernelGGL(k_paired48, dim3(n), dim3(128), 0, st, d_jobs, d_results, n, (const uint32_t*)nullptr, (const lzf::seg_job*)s.ctx.st);
         if (hipGetLastError() != hipSuccess) rc = LZF_E_HIP;
@@ -300,7 +423,13 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
         if (use_compact) LAUNCH(k_compact_dry, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, 0u);
 #else
         if (use_team) LAUNCH(lzf::lzf_compress_team_kernel, dim3(n_jobs), dim3(192), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, fresh_only ? 1u : 0u);
-        else if (use_compact) LAUNCH(k_compact, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, fresh_only ? 1u : 0u);
+        else if (use_compact) {
+            uint32_t pad = 0;
+#ifdef LZF_ANALYSIS      // LZF_COMPACT_PAD_LDS = bytes of unused LDS per wavefront: fewer resident waves per CU (the residency experiment)
+            { static const uint32_t e = [] { const char* v = getenv("LZF_COMPACT_PAD_LDS"); return v ? (uint32_t)atol(v) : 0u; }(); pad = e; }
+#endif
+            LAUNCH(k_compact, dim3(n_jobs), dim3(64), pad, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, fresh_only ? 1u : 0u);
+        }
 #endif
         if (!fresh_only) LAUNCH(k_general_u32, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, use_compact, (const uint32_t*)perm);
     }

@@ -98,7 +98,14 @@ struct seg_ctx {
     uint32_t* by_len;            // [n_jobs]  chunk / tile stages: grid row -> job, longest input first (null: identity)
     uint32_t rec_by_len;         // the records stage follows by_len too (64 jobs and more; measured: below that its own order is quicker)
     uint32_t dbg_force;          // analysis library only (LZF_SEG_FORCE): 1 = stagers of odd jobs give up, 2 = resolvers of odd jobs give up
+    // A call's jobs may go through the last two stages in GROUPS (capi.hip: the next group's records stage runs under the resolve
+    // stage of the one before): a launch then serves ranks [g_off, g_off + g_n) of by_len[] (which is the jobs by sequences then).
+    // One group: g_off = 0, g_n = n_jobs, grouped = 0.
+    uint32_t g_off, g_n, grouped;
+    uint32_t res_prio;           // the resolve stage's wavefronts raise their issue priority (grouped calls: they share their SIMDs with the next group's records stage)
 };
+// grid row / workgroup index of a group's launch -> job
+__device__ __forceinline__ uint32_t seg_job_of(const seg_ctx& c, uint32_t i) { return c.by_len ? c.by_len[i + c.g_off] : i + c.g_off; }
 constexpr uint32_t kSegRegion = 256, kSegChunk = 64u * kSegRegion, kSegOverlap = 2048, kSegStride = kSegChunk - kSegOverlap;
 constexpr uint32_t kSegChunkWords = kSegChunk / 32u, kSegTile = 2048;
 __global__ void lzf_seg_plan_kernel(seg_ctx c);
@@ -106,6 +113,7 @@ __global__ void lzf_seg_plan_kernel(seg_ctx c);
 // sequences and dealt out in rows of n_cu, every other row reversed, so that the blocks that share a CU (workgroups k, k + n_cu,
 // k + 2 n_cu ... land on the same CU) are a slow one with fast ones: the launch ends with its slowest CU
 __global__ void lzf_seg_order_kernel(seg_ctx c);
+__global__ void lzf_seg_rank_kernel(seg_ctx c, uint32_t* __restrict__ by_tok);
 // the same batches: grid row -> job for the chunk / tile stages, longest input first (a launch ends with its last rows)
 __global__ void lzf_seg_by_len_kernel(seg_ctx c);
 __global__ void lzf_seg_parse_kernel(seg_ctx c);

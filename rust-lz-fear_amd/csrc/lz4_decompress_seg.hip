@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void lzf_seg_plan_kernel(seg_ctx c) {
 __global__ __launch_bounds__(64) void lzf_seg_parse_kernel(seg_ctx c) {
     __shared__ __attribute__((aligned(16))) uint8_t cbufs[16u + kCB + 16u];
     __shared__ __attribute__((aligned(16))) uint32_t rowsA[64u * 8u], rowsB[64u * 8u];
-    const uint32_t j = c.by_len ? c.by_len[blockIdx.y] : blockIdx.y;
+    const uint32_t j = seg_job_of(c, blockIdx.y);
     const seg_job sj = c.st[j];
     if (!sj.eligible) return;
     const uint32_t lane = threadIdx.x & 63u;
@@ -444,8 +444,8 @@ __global__ __launch_bounds__(64) void lzf_seg_seam_kernel(seg_ctx c) {
     constexpr uint32_t kWin = 2048;                                   // compressed bytes a staged window covers
     __shared__ __attribute__((aligned(16))) uint8_t wbytes[kWin + 128u];
     __shared__ uint32_t wbits[kWin / 32u + 2u];
-    const uint32_t j = blockIdx.x;
-    if (j >= c.n_jobs) return;
+    if (blockIdx.x >= c.g_n) return;
+    const uint32_t j = c.grouped ? seg_job_of(c, blockIdx.x) : blockIdx.x;
     const seg_job sj = c.st[j];
     if (!sj.eligible) return;
     const uint32_t lane = threadIdx.x & 63u;
@@ -629,12 +629,40 @@ __device__ __forceinline__ Tok tile_decode(const TileCtx& t, uint32_t p) {
     k.M = M + 4u;
     return k;
 }
+// The common shape of a sequence — lengths with at most one extension byte each, the token, its literals' end and the offset inside
+// the staged bytes, not the input's last bytes — from two unaligned LDS words: the same values tile_decode returns.  Lanes it
+// cannot serve come back `slow` (tile_decode takes them: long runs, the end of the input, every error).
+__device__ __forceinline__ Tok tile_decode_quick(const TileCtx& t, uint32_t p, bool act, bool& slow) {
+    Tok k; k.err = false;
+    const uint32_t r = act ? p - t.tstart : 0u;                              // (a token of this tile: r < kSegTile)
+    uint32_t w, w2;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(t.stage_a + r) : "memory");
+    const uint32_t L0 = (w >> 4) & 15u, M0 = w & 15u, b1 = (w >> 8) & 255u;
+    const bool lx = L0 == 15u, mx = M0 == 15u;
+    const uint32_t L = L0 + (lx ? b1 : 0u);
+    const uint32_t q = p + 1u + (lx ? 1u : 0u);                              // first literal
+    const uint32_t q2 = q + L, r2 = q2 - t.tstart;                           // the offset
+    bool ok = act && !(lx && b1 == 255u) && r2 + 4u <= kTileStage && q2 + 3u <= t.len;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w2) : "v"(t.stage_a + (ok ? r2 : 0u)) : "memory");
+    const uint32_t mext = (w2 >> 16) & 255u;
+    ok = ok && !(mx && mext == 255u);
+    k.L = ok ? L : 0u; k.src = ok ? q : 0u; k.off = ok ? (w2 & 0xFFFFu) : 0u; k.M = ok ? M0 + 4u + (mx ? mext : 0u) : 0u;
+    slow = act && !ok;
+    return k;
+}
+// one token per active lane: the quick form, tile_decode for what it leaves
+__device__ __forceinline__ Tok tile_decode_lanes(const TileCtx& t, uint32_t p, bool act) {
+    bool slow;
+    Tok k = tile_decode_quick(t, p, act, slow);
+    if (__any(slow)) { if (slow) k = tile_decode(t, p); }
+    return k;
+}
 }  // namespace
 
 __global__ __launch_bounds__(64) void lzf_seg_tilesum_kernel(seg_ctx c) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kTileStage];
     __shared__ uint16_t list[kTileTokMax + 64u];
-    const uint32_t j = c.by_len ? c.by_len[blockIdx.y] : blockIdx.y;
+    const uint32_t j = seg_job_of(c, blockIdx.y);
     const seg_job sj = c.st[j];
     if (!sj.eligible || sj.failed) return;
     const uint32_t lane = threadIdx.x & 63u;
@@ -647,8 +675,9 @@ __global__ __launch_bounds__(64) void lzf_seg_tilesum_kernel(seg_ctx c) {
         TileCtx tc{t * kSegTile, lds_addr(stage), len, in};
         uint32_t sum = 0; bool err = false;
         for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
-            if (i0 + lane < n) {
-                const Tok k = tile_decode(tc, tc.tstart + list[i0 + lane]);
+            {
+                const bool act = i0 + lane < n;
+                const Tok k = tile_decode_lanes(tc, tc.tstart + (act ? list[i0 + lane] : 0u), act);
                 err = err || k.err;
                 sum += k.L + k.M;                          // (each <= 2^26 + 4, at most 11 per lane)
             }
@@ -663,8 +692,8 @@ __global__ __launch_bounds__(64) void lzf_seg_tilesum_kernel(seg_ctx c) {
 }
 
 __global__ __launch_bounds__(64) void lzf_seg_scan_kernel(seg_ctx c) {
-    const uint32_t j = blockIdx.x;
-    if (j >= c.n_jobs) return;
+    if (blockIdx.x >= c.g_n) return;
+    const uint32_t j = c.grouped ? seg_job_of(c, blockIdx.x) : blockIdx.x;
     const seg_job sj = c.st[j];
     if (!sj.eligible || sj.failed) return;
     const uint32_t lane = threadIdx.x & 63u;
@@ -718,8 +747,7 @@ __global__ __launch_bounds__(64) void lzf_seg_scan_kernel(seg_ctx c) {
 __global__ __launch_bounds__(64) void lzf_seg_records_kernel(seg_ctx c) {
     __shared__ __attribute__((aligned(16))) uint8_t stage[kTileStage];
     __shared__ uint16_t list[kTileTokMax + 64u];
-    __shared__ uint32_t s_end[64], s_mo[64], s_lvl[64], s_pm[64];
-    const uint32_t j = (c.by_len && c.rec_by_len) ? c.by_len[blockIdx.y] : blockIdx.y;
+    const uint32_t j = (c.rec_by_len || c.grouped) ? seg_job_of(c, blockIdx.y) : blockIdx.y;
     const seg_job sj = c.st[j];
     if (!sj.eligible || sj.failed) return;
     const uint32_t lane = threadIdx.x & 63u;
@@ -742,8 +770,7 @@ __global__ __launch_bounds__(64) void lzf_seg_records_kernel(seg_ctx c) {
         for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
             const uint32_t nb = n - i0 < 64u ? n - i0 : 64u;
             const bool act = lane < nb;
-            Tok k; k.L = 0; k.M = 0; k.off = 0; k.src = 0; k.err = false;
-            if (act) k = tile_decode(tc, tc.tstart + list[i0 + lane]);
+            const Tok k = tile_decode_lanes(tc, tc.tstart + (act ? list[i0 + lane] : 0u), act);
             const uint32_t tot = k.L + k.M;
             const uint32_t incl = wave_scan_add(tot);
             const uint32_t ob = obase;
@@ -769,37 +796,32 @@ __global__ __launch_bounds__(64) void lzf_seg_records_kernel(seg_ctx c) {
             const bool has = act && M != 0u;
             const uint32_t span = M < off ? M : off;
             const uint32_t s0 = mo - off, e0 = s0 + span;
-            __syncthreads();
-            s_end[lane] = act ? mo + M : 0xFFFFFFFFu;
-            s_mo[lane] = act ? mo : 0xFFFFFFFFu;
             uint32_t lvl = has ? 1u : 0u;
             const bool dep = has && e0 > ob;             // the source reaches into the batch
-            uint32_t ilo = 0, ihi = 0; bool any_dep = false;
+            // (lane values are exchanged by ds_bpermute: no LDS memory, no address arithmetic — every lane is active here)
+            auto from_lane = [](uint32_t l, uint32_t v) -> uint32_t { return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((l & 63u) << 2), (int)v); };
             if (__any(dep)) {
-                __syncthreads();
+                const uint32_t endv = act ? mo + M : 0xFFFFFFFFu, mov = act ? mo : 0xFFFFFFFFu;
                 uint32_t a = 0, bb = 0;                   // a = #lanes with end <= s0; bb = #lanes with mo < e0
 #pragma unroll
                 for (uint32_t step = 32u; step; step >>= 1) {
-                    if (s_end[(a + step - 1u) & 63u] <= s0) a += step;
-                    if (s_mo[(bb + step - 1u) & 63u] < e0) bb += step;
+                    if (from_lane(a + step - 1u, endv) <= s0) a += step;
+                    if (from_lane(bb + step - 1u, mov) < e0) bb += step;
                 }
-                ilo = a; ihi = bb - 1u;
-                any_dep = dep && bb >= 1u && ilo <= ihi && ihi < lane;
-            }
-            if (__any(any_dep)) {
-                for (uint32_t it = 0; it < 64u; ++it) {
-                    __syncthreads();
-                    s_lvl[lane] = lvl;
-                    s_pm[lane] = wave_scan_max(lvl);
-                    __syncthreads();
-                    uint32_t nl = lvl;
-                    if (any_dep) {
-                        const uint32_t m = ihi - ilo <= 1u ? (s_lvl[ilo] > s_lvl[ihi] ? s_lvl[ilo] : s_lvl[ihi]) : s_pm[ihi];
-                        nl = 1u + m;
+                const uint32_t ilo = a, ihi = bb - 1u;
+                const bool any_dep = dep && bb >= 1u && ilo <= ihi && ihi < lane;
+                if (__any(any_dep)) {
+                    const bool wide = any_dep && ihi - ilo > 1u;
+                    const bool any_wide = __any(wide);
+                    for (uint32_t it = 0; it < 64u; ++it) {
+                        const uint32_t la = from_lane(ilo, lvl), lb = from_lane(ihi, lvl);
+                        uint32_t m = la > lb ? la : lb;
+                        if (any_wide) { const uint32_t pm = from_lane(ihi, wave_scan_max(lvl)); if (wide) m = pm; }
+                        const uint32_t nl = any_dep ? 1u + m : lvl;
+                        const bool ch = nl != lvl;
+                        lvl = nl;
+                        if (!__any(ch)) break;
                     }
-                    const bool ch = nl != lvl;
-                    lvl = nl;
-                    if (!__any(ch)) break;
                 }
             }
             // ---- sub-batches and classes
@@ -865,7 +887,8 @@ __global__ __launch_bounds__(1024) void lzf_seg_by_len_kernel(seg_ctx c) {
     for (uint32_t k = 0; k < n; ++k) { const uint32_t o = cost[k]; r += (o > mine || (o == mine && k < i)) ? 1u : 0u; }
     c.by_len[r] = i;
 }
-__global__ __launch_bounds__(1024) void lzf_seg_order_kernel(seg_ctx c) {
+// the jobs of the call by their sequences, most first (grouped calls: which jobs go through the last two stages together)
+__global__ __launch_bounds__(1024) void lzf_seg_rank_kernel(seg_ctx c, uint32_t* __restrict__ by_tok) {
     __shared__ uint32_t cost[1024];
     const uint32_t i = threadIdx.x, n = c.n_jobs;
     if (i < n) { const seg_job s = c.st[i]; cost[i] = (s.eligible && !s.failed) ? s.ntok : 0u; }
@@ -874,10 +897,22 @@ __global__ __launch_bounds__(1024) void lzf_seg_order_kernel(seg_ctx c) {
     const uint32_t mine = cost[i];
     uint32_t r = 0;
     for (uint32_t k = 0; k < n; ++k) { const uint32_t o = cost[k]; r += (o > mine || (o == mine && k < i)) ? 1u : 0u; }
+    by_tok[r] = i;
+}
+__global__ __launch_bounds__(1024) void lzf_seg_order_kernel(seg_ctx c) {
+    __shared__ uint32_t cost[1024];
+    const uint32_t i = threadIdx.x, n = c.g_n;                     // (the ranks of this launch's group)
+    const uint32_t job = i < n ? (c.grouped ? seg_job_of(c, i) : i) : 0u;
+    if (i < n) { const seg_job s = c.st[job]; cost[i] = (s.eligible && !s.failed) ? s.ntok : 0u; }
+    __syncthreads();
+    if (i >= n) return;
+    const uint32_t mine = cost[i];
+    uint32_t r = 0;
+    for (uint32_t k = 0; k < n; ++k) { const uint32_t o = cost[k]; r += (o > mine || (o == mine && k < i)) ? 1u : 0u; }
     const uint32_t ncu = c.n_cu ? c.n_cu : 256u;
     const uint32_t row = r / ncu, col = r % ncu;
     const uint32_t rowlen = n - row * ncu < ncu ? n - row * ncu : ncu;
-    c.order[row * ncu + ((row & 1u) ? rowlen - 1u - col : col)] = i;
+    c.order[c.g_off + row * ncu + ((row & 1u) ? rowlen - 1u - col : col)] = job;
 }
 
 // =====================================================================================================================
@@ -902,11 +937,12 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[64 + R];
     uint8_t* const ring = lds_all + 64;
     uint32_t* const ctl = reinterpret_cast<uint32_t*>(lds_all);      // [0] staged tickets, [1] resolved tickets, [3] a wave gave up
-    if (blockIdx.x >= c.n_jobs) return;
-    const uint32_t j = c.order ? c.order[blockIdx.x] : blockIdx.x;
+    if (blockIdx.x >= c.g_n) return;
+    const uint32_t j = c.order ? c.order[c.g_off + blockIdx.x] : c.grouped ? seg_job_of(c, blockIdx.x) : blockIdx.x;
     const seg_job sj = c.st[j];
     if (!sj.eligible || sj.failed) return;
     if (c.ring_bytes != (uint32_t)R) return;           // (the records were classed for another ring: leave the job to the pair kernel)
+    if (c.res_prio) __builtin_amdgcn_s_setprio(3);     // the block's chain: ahead of the throughput kernels that share the SIMD
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const lzf_decompress_job job = c.jobs[j];
