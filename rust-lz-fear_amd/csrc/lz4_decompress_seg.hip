@@ -225,119 +225,102 @@ __global__ __launch_bounds__(64) void lzf_seg_parse_kernel(seg_ctx c) {
             for (;;) {
 #ifndef LZF_SEG_NOASM
                 // ---- plain hops, hand-scheduled (the walks are chains of dependent instructions: every one counts; hipcc's version of
-                //      this loop spends ~20 scalar instructions per hop on lane masks).  exec stays full; a lane is in the loop while
-                //      lim != 0 and leaves by lim = 0 when its hop is not a plain one: past the stop position, parked for the general
-                //      routine, on a token marked in row A (mode 1), or because the previous token's match length turned out to go on
-                //      (0xFF extension byte: r steps back to that token, which the general routine then takes).
+                //      this loop spends ~20 scalar instructions per hop on lane masks).  A lane is in the loop while it is in EXEC and leaves it
+                //      for good when its hop is not a plain one: past the stop position, parked for the general routine, on a token marked in
+                //      row A (mode 1), or because the previous token's match length turned out to go on (0xFF extension byte: r steps back
+                //      to that token, which the general routine then takes).  21 vector instructions per hop (mode 1: 26; 34 / 40 with the
+                //      lanes' state in selects instead of EXEC).  mxp = the byte in front of the token that means "not plain": 0xFF when the
+                //      previous token's match nibble was 15, else 0x100 (no byte has that value).
                 {
-                    uint32_t mxp = 0, rprev = r, lim = (go && !merged && r < stop) ? stop : 0u, mg = merged ? 1u : 0u;
-                    uint32_t a_, w_, t_, x_, rn_, mxn_, y_, mk_;
-                    unsigned long long sgo, sy;
-                    const uint32_t rowa = lds_addr(rowsA) + lane * 4u, rowd = lds_addr(rowsB) - lds_addr(rowsA);
+                    uint32_t mxp = 0x100u, rprev = r, mg = merged ? 1u : 0u;
+                    const uint32_t stopv = stop;
+                    const unsigned long long m0 = __ballot(go && !merged && r < stop);
+                    uint32_t a_, w_, t_, x_, rn_, mk_;
+                    unsigned long long sv, sc;
+                    // row word of position r: rows[(r >> 5) - 8 * lane][lane] = rowsA + ((r >> 5) << 8) + 4 * lane - (lane << 11)  (mod 2^32)
+                    const uint32_t rowa2 = lds_addr(rowsA) + lane * 4u - (lane << 11), rowd = lds_addr(rowsB) - lds_addr(rowsA);
+                    const uint32_t vzero = 0u, vff = 0xFFu, v100 = 0x100u;
                     if (mode == 0) {
                         asm volatile(
+                            "s_mov_b64 %[sv], exec\n\t"
+                            "s_and_b64 exec, exec, %[m0]\n\t"
+                            "s_cbranch_execz Ld%=\n"
                             "Lw%=:\n\t"
-                            "v_cmp_ne_u32 vcc, 0, %[lim]\n\t"
-                            "s_cbranch_vccz Ld%=\n\t"
-                            "v_cndmask_b32 %[a], 0, %[r], vcc\n\t"
-                            "v_add_u32 %[a], %[cbm1], %[a]\n\t"
+                            "v_add_u32 %[a], %[cbm1], %[r]\n\t"
                             "ds_read_b32 %[w], %[a]\n\t"
                             "s_waitcnt lgkmcnt(0)\n\t"
-                            "v_and_b32 %[t], 0xff, %[w]\n\t"
-                            "v_cmp_eq_u32 vcc, 0xff, %[t]\n\t"
-                            "v_cndmask_b32 %[t], 0, %[mxp], vcc\n\t"
-                            "v_cmp_ne_u32 vcc, 0, %[t]\n\t"
+                            "v_cmp_eq_u32_sdwa vcc, %[w], %[mxp] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
                             "v_cndmask_b32 %[r], %[r], %[rprev], vcc\n\t"
-                            "v_cndmask_b32_e64 %[lim], %[lim], 0, vcc\n\t"
-                            "v_cmp_lt_u32_e64 %[sgo], %[r], %[lim]\n\t"
+                            "s_andn2_b64 exec, exec, vcc\n\t"
+                            "v_cmpx_lt_u32 vcc, %[r], %[stop]\n\t"
                             "v_bfe_u32 %[x], %[w], 12, 4\n\t"
-                            "v_bfe_u32 %[t], %[w], 16, 8\n\t"
                             "v_cmp_eq_u32 vcc, 15, %[x]\n\t"
-                            "v_cndmask_b32 %[t], 0, %[t], vcc\n\t"
+                            "v_cndmask_b32_sdwa %[t], %[vz], %[w], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
                             "v_addc_co_u32 %[rn], vcc, %[x], %[t], vcc\n\t"
                             "v_add3_u32 %[rn], %[rn], %[r], 3\n\t"
-                            "v_bfe_u32 %[x], %[w], 8, 4\n\t"
-                            "v_cmp_eq_u32 vcc, 15, %[x]\n\t"
-                            "v_cndmask_b32 %[mxn], 0, 1, vcc\n\t"
-                            "v_add_u32 %[rn], %[rn], %[mxn]\n\t"
                             "v_and_b32 %[t], 0xfff000, %[w]\n\t"
-                            "v_cmp_ne_u32 vcc, 0xfff000, %[t]\n\t"
-                            "v_cmp_gt_u32_e64 %[sy], %[fe], %[rn]\n\t"
-                            "s_and_b64 vcc, vcc, %[sy]\n\t"
-                            "s_and_b64 vcc, vcc, %[sgo]\n\t"
-                            "v_sub_u32 %[t], %[r], %[rb0]\n\t"
-                            "v_cndmask_b32 %[t], 0, %[t], vcc\n\t"
-                            "v_lshrrev_b32 %[x], 5, %[t]\n\t"
-                            "v_lshl_add_u32 %[x], %[x], 8, %[rowa]\n\t"
-                            "v_cndmask_b32 %[a], 0, 1, vcc\n\t"
-                            "v_lshlrev_b32 %[a], %[t], %[a]\n\t"
+                            "v_cmpx_ne_u32 vcc, 0xfff000, %[t]\n\t"
+                            "v_and_b32 %[x], 0xf00, %[w]\n\t"
+                            "v_cmp_eq_u32 vcc, 0xf00, %[x]\n\t"
+                            "v_addc_co_u32 %[rn], %[sc], 0, %[rn], vcc\n\t"
+                            "v_cndmask_b32 %[mxp], %[v100], %[vff], vcc\n\t"
+                            "v_cmpx_gt_u32 vcc, %[fe], %[rn]\n\t"
+                            "v_lshrrev_b32 %[x], 5, %[r]\n\t"
+                            "v_lshl_add_u32 %[x], %[x], 8, %[rowa2]\n\t"
+                            "v_lshlrev_b32 %[a], %[r], 1\n\t"
                             "ds_or_b32 %[x], %[a]\n\t"
-                            "v_cndmask_b32 %[rprev], %[rprev], %[r], vcc\n\t"
-                            "v_cndmask_b32 %[r], %[r], %[rn], vcc\n\t"
-                            "v_cndmask_b32 %[mxp], 0, %[mxn], vcc\n\t"
-                            "v_cndmask_b32 %[lim], 0, %[lim], vcc\n\t"
-                            "s_branch Lw%=\n"
-                            "Ld%=:"
-                            : [r] "+v"(r), [rprev] "+v"(rprev), [mxp] "+v"(mxp), [lim] "+v"(lim),
-                              [a] "=&v"(a_), [w] "=&v"(w_), [t] "=&v"(t_), [x] "=&v"(x_), [rn] "=&v"(rn_), [mxn] "=&v"(mxn_), [sgo] "=&s"(sgo), [sy] "=&s"(sy)
-                            : [cbm1] "s"(cbuf_a - 1u), [fe] "s"(fe), [rb0] "v"(rb0), [rowa] "v"(rowa)
+                            "v_mov_b32 %[rprev], %[r]\n\t"
+                            "v_mov_b32 %[r], %[rn]\n\t"
+                            "s_cbranch_execnz Lw%=\n"
+                            "Ld%=:\n\t"
+                            "s_mov_b64 exec, %[sv]"
+                            : [r] "+v"(r), [rprev] "+v"(rprev), [mxp] "+v"(mxp),
+                              [a] "=&v"(a_), [w] "=&v"(w_), [t] "=&v"(t_), [x] "=&v"(x_), [rn] "=&v"(rn_), [sv] "=&s"(sv), [sc] "=&s"(sc)
+                            : [cbm1] "s"(cbuf_a - 1u), [fe] "s"(fe), [stop] "v"(stopv), [rowa2] "v"(rowa2), [vz] "v"(vzero), [vff] "v"(vff), [v100] "v"(v100), [m0] "s"(m0)
                             : "vcc", "memory");
                     } else {
                         asm volatile(
+                            "s_mov_b64 %[sv], exec\n\t"
+                            "s_and_b64 exec, exec, %[m0]\n\t"
+                            "s_cbranch_execz Ld%=\n"
                             "Lw%=:\n\t"
-                            "v_cmp_ne_u32 vcc, 0, %[lim]\n\t"
-                            "s_cbranch_vccz Ld%=\n\t"
-                            "v_cndmask_b32 %[a], 0, %[r], vcc\n\t"
-                            "v_sub_u32 %[y], %[r], %[rb0]\n\t"
-                            "v_add_u32 %[a], %[cbm1], %[a]\n\t"
-                            "v_cndmask_b32 %[y], 0, %[y], vcc\n\t"
+                            "v_add_u32 %[a], %[cbm1], %[r]\n\t"
+                            "v_lshrrev_b32 %[x], 5, %[r]\n\t"
                             "ds_read_b32 %[w], %[a]\n\t"
-                            "v_lshrrev_b32 %[x], 5, %[y]\n\t"
-                            "v_lshl_add_u32 %[x], %[x], 8, %[rowa]\n\t"
+                            "v_lshl_add_u32 %[x], %[x], 8, %[rowa2]\n\t"
                             "ds_read_b32 %[mk], %[x]\n\t"
                             "s_waitcnt lgkmcnt(0)\n\t"
-                            "v_lshrrev_b32 %[mk], %[y], %[mk]\n\t"
-                            "v_and_b32 %[mk], 1, %[mk]\n\t"
-                            "v_and_b32 %[t], 0xff, %[w]\n\t"
-                            "v_cmp_eq_u32 vcc, 0xff, %[t]\n\t"
-                            "v_cndmask_b32 %[t], 0, %[mxp], vcc\n\t"
-                            "v_cmp_ne_u32 vcc, 0, %[t]\n\t"
+                            "v_cmp_eq_u32_sdwa vcc, %[w], %[mxp] src0_sel:BYTE_0 src1_sel:DWORD\n\t"
                             "v_cndmask_b32 %[r], %[r], %[rprev], vcc\n\t"
-                            "v_cndmask_b32_e64 %[lim], %[lim], 0, vcc\n\t"
-                            "v_cmp_lt_u32_e64 %[sgo], %[r], %[lim]\n\t"
-                            "v_cmp_ne_u32 vcc, 0, %[mk]\n\t"
-                            "s_and_b64 vcc, vcc, %[sgo]\n\t"
-                            "v_cndmask_b32_e64 %[mg], %[mg], 1, vcc\n\t"
-                            "s_andn2_b64 %[sgo], %[sgo], vcc\n\t"
+                            "s_andn2_b64 exec, exec, vcc\n\t"
+                            "v_cmpx_lt_u32 vcc, %[r], %[stop]\n\t"
+                            "v_lshrrev_b32 %[mk], %[r], %[mk]\n\t"
+                            "v_and_b32 %[mk], 1, %[mk]\n\t"
+                            "v_or_b32 %[mg], %[mg], %[mk]\n\t"                 /* on a token of the pass-0 chain: merged */
+                            "v_cmpx_eq_u32 vcc, 0, %[mk]\n\t"
                             "v_bfe_u32 %[mk], %[w], 12, 4\n\t"
-                            "v_bfe_u32 %[t], %[w], 16, 8\n\t"
                             "v_cmp_eq_u32 vcc, 15, %[mk]\n\t"
-                            "v_cndmask_b32 %[t], 0, %[t], vcc\n\t"
+                            "v_cndmask_b32_sdwa %[t], %[vz], %[w], vcc dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n\t"
                             "v_addc_co_u32 %[rn], vcc, %[mk], %[t], vcc\n\t"
                             "v_add3_u32 %[rn], %[rn], %[r], 3\n\t"
-                            "v_bfe_u32 %[mk], %[w], 8, 4\n\t"
-                            "v_cmp_eq_u32 vcc, 15, %[mk]\n\t"
-                            "v_cndmask_b32 %[mxn], 0, 1, vcc\n\t"
-                            "v_add_u32 %[rn], %[rn], %[mxn]\n\t"
                             "v_and_b32 %[t], 0xfff000, %[w]\n\t"
-                            "v_cmp_ne_u32 vcc, 0xfff000, %[t]\n\t"
-                            "v_cmp_gt_u32_e64 %[sy], %[fe], %[rn]\n\t"
-                            "s_and_b64 vcc, vcc, %[sy]\n\t"
-                            "s_and_b64 vcc, vcc, %[sgo]\n\t"
+                            "v_cmpx_ne_u32 vcc, 0xfff000, %[t]\n\t"
+                            "v_and_b32 %[mk], 0xf00, %[w]\n\t"
+                            "v_cmp_eq_u32 vcc, 0xf00, %[mk]\n\t"
+                            "v_addc_co_u32 %[rn], %[sc], 0, %[rn], vcc\n\t"
+                            "v_cndmask_b32 %[mxp], %[v100], %[vff], vcc\n\t"
+                            "v_cmpx_gt_u32 vcc, %[fe], %[rn]\n\t"
                             "v_add_u32 %[x], %[x], %[rowd]\n\t"                 /* the same word of row B */
-                            "v_cndmask_b32 %[a], 0, 1, vcc\n\t"
-                            "v_lshlrev_b32 %[a], %[y], %[a]\n\t"
+                            "v_lshlrev_b32 %[a], %[r], 1\n\t"
                             "ds_or_b32 %[x], %[a]\n\t"
-                            "v_cndmask_b32 %[rprev], %[rprev], %[r], vcc\n\t"
-                            "v_cndmask_b32 %[r], %[r], %[rn], vcc\n\t"
-                            "v_cndmask_b32 %[mxp], 0, %[mxn], vcc\n\t"
-                            "v_cndmask_b32 %[lim], 0, %[lim], vcc\n\t"
-                            "s_branch Lw%=\n"
-                            "Ld%=:"
-                            : [r] "+v"(r), [rprev] "+v"(rprev), [mxp] "+v"(mxp), [lim] "+v"(lim), [mg] "+v"(mg),
-                              [a] "=&v"(a_), [w] "=&v"(w_), [t] "=&v"(t_), [x] "=&v"(x_), [rn] "=&v"(rn_), [mxn] "=&v"(mxn_), [y] "=&v"(y_), [mk] "=&v"(mk_),
-                              [sgo] "=&s"(sgo), [sy] "=&s"(sy)
-                            : [cbm1] "s"(cbuf_a - 1u), [fe] "s"(fe), [rb0] "v"(rb0), [rowa] "v"(rowa), [rowd] "v"(rowd)
+                            "v_mov_b32 %[rprev], %[r]\n\t"
+                            "v_mov_b32 %[r], %[rn]\n\t"
+                            "s_cbranch_execnz Lw%=\n"
+                            "Ld%=:\n\t"
+                            "s_mov_b64 exec, %[sv]"
+                            : [r] "+v"(r), [rprev] "+v"(rprev), [mxp] "+v"(mxp), [mg] "+v"(mg),
+                              [a] "=&v"(a_), [w] "=&v"(w_), [t] "=&v"(t_), [x] "=&v"(x_), [rn] "=&v"(rn_), [mk] "=&v"(mk_), [sv] "=&s"(sv), [sc] "=&s"(sc)
+                            : [cbm1] "s"(cbuf_a - 1u), [fe] "s"(fe), [stop] "v"(stopv), [rowa2] "v"(rowa2), [rowd] "v"(rowd), [vz] "v"(vzero), [vff] "v"(vff), [v100] "v"(v100), [m0] "s"(m0)
                             : "vcc", "memory");
                     }
                     merged = mg != 0u;
