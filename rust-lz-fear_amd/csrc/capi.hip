@@ -283,9 +283,15 @@ struct SegLanes {
 SegLanes* seg_lanes() {
     static SegLanes* lanes = [] {
         SegLanes* L = new SegLanes();
+        // High-priority streams: the runtime keeps a pool of hardware queues per priority (four each by default), so these three do not
+        // end up sharing a queue with the application's own streams — a resolve stage queued behind the caller's next records stage
+        // would serialise the call (measured: 49 blocks 13.4 ms instead of 8.0 with one application side stream alive) — and the
+        // resolve stage, the chain of the call, is dispatched ahead of the throughput kernels.
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) { (void)hipGetLastError(); least = greatest = 0; }
         bool ok = true;
         for (uint32_t i = 0; i < kSegMaxGroups - 1u && ok; ++i)
-            ok = hipStreamCreateWithFlags(&L->s[i], hipStreamNonBlocking) == hipSuccess &&
+            ok = hipStreamCreateWithPriority(&L->s[i], hipStreamNonBlocking, greatest) == hipSuccess &&
                  hipEventCreateWithFlags(&L->front[i], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreateWithFlags(&L->done[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) (void)hipGetLastError();

@@ -23,7 +23,7 @@ namespace lzf {
 namespace {
 
 constexpr uint32_t S = kSegRegion;
-constexpr uint32_t kCB = kSegChunk + 64u;          // staged bytes of a chunk: the chunk + room for token heads
+constexpr uint32_t kCB = kSegChunk;                // staged bytes of a chunk (with the rows: 20 480 bytes of LDS, eight chunks per CU; tokens that reach over the end take the general routine)
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kLenClamp = 1u << 26;           // a literal / match length beyond this sends the job to the pair kernel
 constexpr uint32_t kTileStage = kSegTile + 128u;   // staged bytes of a tile
@@ -168,8 +168,12 @@ __global__ __launch_bounds__(256) void lzf_seg_plan_kernel(seg_ctx c) {
 // first literal-length extension byte, ...].  Tokens a plain hop cannot express (0xFF length bytes, the last 24 bytes of
 // the input) go through the general routine.
 __global__ __launch_bounds__(64) void lzf_seg_parse_kernel(seg_ctx c) {
-    __shared__ __attribute__((aligned(16))) uint8_t cbufs[16u + kCB + 16u];
-    __shared__ __attribute__((aligned(16))) uint32_t rowsA[64u * 8u], rowsB[64u * 8u];
+    // one array: rows A, rows B, the chunk's bytes.  A hop reads 4 bytes from position - 1: for the chunk's first byte that is the last
+    // byte of row B (any value: a walk's first hop does not look at it), and no hop lands on the last two bytes (see `fe`).
+    __shared__ __attribute__((aligned(16))) uint8_t lds_parse[2u * 64u * 8u * 4u + kCB];
+    static_assert(sizeof(lds_parse) == 20480, "eight chunks per CU: an eighth of 160 KiB each");
+    uint32_t* const rowsA = reinterpret_cast<uint32_t*>(lds_parse);
+    uint32_t* const rowsB = rowsA + 64u * 8u;
     const uint32_t j = seg_job_of(c, blockIdx.y);
     const seg_job sj = c.st[j];
     if (!sj.eligible) return;
@@ -177,7 +181,7 @@ __global__ __launch_bounds__(64) void lzf_seg_parse_kernel(seg_ctx c) {
     const lzf_decompress_job job = c.jobs[j];
     cgu8* __restrict__ in = as_global(job.input);
     const uint32_t len = (uint32_t)job.input_len;
-    uint8_t* const cbuf = cbufs + 16u;
+    uint8_t* const cbuf = lds_parse + 2u * 64u * 8u * 4u;
     const uint32_t cbuf_a = lds_addr(cbuf);
     // word w of a lane's row lives at [w * 64 + lane]: the 64 lanes of an access hit 64 different banks
 #define ROWA(w) rowsA[(w) * 64u + lane]
@@ -206,12 +210,14 @@ __global__ __launch_bounds__(64) void lzf_seg_parse_kernel(seg_ctx c) {
                 }
             }
             { const uint32_t t0 = avail & ~15u; if (t0 < kCB && lane < (avail & 15u)) cbuf[t0 + lane] = g[t0 + lane]; }   // the ragged end of the input
-            if (lane < 4u) reinterpret_cast<uint32_t*>(cbufs)[lane] = 0u;      // the byte in front of the chunk is never an extension byte we trust
         }
 #pragma unroll
         for (uint32_t i = 0; i < 8u; ++i) { ROWA(i) = 0u; ROWB(i) = 0u; }
         const uint32_t room = len - cstart;                                      // bytes from the chunk start to the end of the input
-        const uint32_t fe = room > 24u ? (room - 24u < kCB ? room - 24u : kCB) : 0u;   // a plain hop lands below fe (chunk-relative)
+        // a plain hop lands below fe (chunk-relative): 24 bytes short of the input's end, and 2 short of the staged bytes — a lane reads the
+        // 4 bytes from its position - 1 wherever it has landed (the extension byte of the token before is checked there), and a read
+        // that crosses the end of the workgroup's LDS returns zeros for all four
+        const uint32_t fe = room > 24u ? (room - 24u < kCB - 2u ? room - 24u : kCB - 2u) : 0u;
         const uint32_t rb0 = lane * S, end_r = rb0 + S;
 
         auto rdb = [&](uint32_t q) -> uint32_t { const uint32_t r_ = q - cstart; if (r_ < kCB) return (uint32_t)cbuf[r_]; return (uint32_t)in[q]; };
@@ -612,34 +618,6 @@ __device__ __forceinline__ Tok tile_decode(const TileCtx& t, uint32_t p) {
     k.M = M + 4u;
     return k;
 }
-// The common shape of a sequence — lengths with at most one extension byte each, the token, its literals' end and the offset inside
-// the staged bytes, not the input's last bytes — from two unaligned LDS words: the same values tile_decode returns.  Lanes it
-// cannot serve come back `slow` (tile_decode takes them: long runs, the end of the input, every error).
-__device__ __forceinline__ Tok tile_decode_quick(const TileCtx& t, uint32_t p, bool act, bool& slow) {
-    Tok k; k.err = false;
-    const uint32_t r = act ? p - t.tstart : 0u;                              // (a token of this tile: r < kSegTile)
-    uint32_t w, w2;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(t.stage_a + r) : "memory");
-    const uint32_t L0 = (w >> 4) & 15u, M0 = w & 15u, b1 = (w >> 8) & 255u;
-    const bool lx = L0 == 15u, mx = M0 == 15u;
-    const uint32_t L = L0 + (lx ? b1 : 0u);
-    const uint32_t q = p + 1u + (lx ? 1u : 0u);                              // first literal
-    const uint32_t q2 = q + L, r2 = q2 - t.tstart;                           // the offset
-    bool ok = act && !(lx && b1 == 255u) && r2 + 4u <= kTileStage && q2 + 3u <= t.len;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w2) : "v"(t.stage_a + (ok ? r2 : 0u)) : "memory");
-    const uint32_t mext = (w2 >> 16) & 255u;
-    ok = ok && !(mx && mext == 255u);
-    k.L = ok ? L : 0u; k.src = ok ? q : 0u; k.off = ok ? (w2 & 0xFFFFu) : 0u; k.M = ok ? M0 + 4u + (mx ? mext : 0u) : 0u;
-    slow = act && !ok;
-    return k;
-}
-// one token per active lane: the quick form, tile_decode for what it leaves
-__device__ __forceinline__ Tok tile_decode_lanes(const TileCtx& t, uint32_t p, bool act) {
-    bool slow;
-    Tok k = tile_decode_quick(t, p, act, slow);
-    if (__any(slow)) { if (slow) k = tile_decode(t, p); }
-    return k;
-}
 }  // namespace
 
 __global__ __launch_bounds__(64) void lzf_seg_tilesum_kernel(seg_ctx c) {
@@ -658,9 +636,8 @@ __global__ __launch_bounds__(64) void lzf_seg_tilesum_kernel(seg_ctx c) {
         TileCtx tc{t * kSegTile, lds_addr(stage), len, in};
         uint32_t sum = 0; bool err = false;
         for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
-            {
-                const bool act = i0 + lane < n;
-                const Tok k = tile_decode_lanes(tc, tc.tstart + (act ? list[i0 + lane] : 0u), act);
+            if (i0 + lane < n) {
+                const Tok k = tile_decode(tc, tc.tstart + list[i0 + lane]);
                 err = err || k.err;
                 sum += k.L + k.M;                          // (each <= 2^26 + 4, at most 11 per lane)
             }
@@ -753,7 +730,8 @@ __global__ __launch_bounds__(64) void lzf_seg_records_kernel(seg_ctx c) {
         for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
             const uint32_t nb = n - i0 < 64u ? n - i0 : 64u;
             const bool act = lane < nb;
-            const Tok k = tile_decode_lanes(tc, tc.tstart + (act ? list[i0 + lane] : 0u), act);
+            Tok k; k.L = 0; k.M = 0; k.off = 0; k.src = 0; k.err = false;
+            if (act) k = tile_decode(tc, tc.tstart + list[i0 + lane]);
             const uint32_t tot = k.L + k.M;
             const uint32_t incl = wave_scan_add(tot);
             const uint32_t ob = obase;
@@ -985,6 +963,10 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
         uint32_t t = 0, staged = 0;                       // tickets resolved; tickets known to be staged (the flag as last read)
         // the records come straight from HBM, two batches ahead (the only loads of this wave: they return in order and in time)
         u32x4 rA = u32x4{0, 0, 0, 0}, rB = u32x4{0, 0, 0, 0};
+#ifdef LZF_SEG_DEEP
+        u32x4 rC = u32x4{0, 0, 0, 0}, rD = u32x4{0, 0, 0, 0};
+        if (n) { rC = recs[128u + lane < n ? 128u + lane : n - 1u]; rD = recs[192u + lane < n ? 192u + lane : n - 1u]; }
+#endif
         if (n) { rA = recs[lane < n ? lane : n - 1u]; rB = recs[64u + lane < n ? 64u + lane : n - 1u]; }
         auto wait_staged = [&](uint32_t tt) -> bool {    // ticket tt published?  (one read of the flag usually covers several tickets)
             if (staged > tt) return true;
@@ -1000,7 +982,12 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
             const u32x4 r = rA;
             asm volatile("" ::: "memory");
             rA = rB;
+#ifdef LZF_SEG_DEEP
+            rB = rC; rC = rD;
+            { const uint32_t ix = i0 + 256u + lane; rD = recs[ix < n ? ix : n - 1u]; }
+#else
             { const uint32_t ix = i0 + 128u + lane; rB = recs[ix < n ? ix : n - 1u]; }
+#endif
             asm volatile("" ::: "memory");
             RT(tm_setup);
             if (!wait_staged(t)) break;
@@ -1418,6 +1405,10 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
         auto wait_resolved = [&](uint32_t tt) { if (tt && !gave_up && !flag_wait_above(1, tt - 1u)) gave_up = true; };
 #endif
         u32x4 rA = u32x4{0, 0, 0, 0}, rB = u32x4{0, 0, 0, 0};
+#ifdef LZF_SEG_DEEP
+        u32x4 rC = u32x4{0, 0, 0, 0}, rD = u32x4{0, 0, 0, 0};
+        if (n) { rC = recs[128u + lane < n ? 128u + lane : n - 1u]; rD = recs[192u + lane < n ? 192u + lane : n - 1u]; }
+#endif
         if (n) { rA = recs[lane < n ? lane : n - 1u]; rB = recs[64u + lane < n ? 64u + lane : n - 1u]; }
         uint32_t prev_end = rb;                          // biased end of the previous sequence
         for (uint32_t i0 = 0; i0 < n && !gave_up; i0 += 64u) {
@@ -1431,7 +1422,12 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
             const uint32_t nsub = __builtin_amdgcn_readlane(r[2] & 0xFFu, (nb - 1u) & 63u) + 1u;
             asm volatile("" ::: "memory");
             rA = rB;
+#ifdef LZF_SEG_DEEP
+            rB = rC; rC = rD;
+            { const uint32_t ix = i0 + 256u + lane; rD = recs[ix < n ? ix : n - 1u]; }
+#else
             { const uint32_t ix = i0 + 128u + lane; rB = recs[ix < n ? ix : n - 1u]; }
+#endif
             asm volatile("" ::: "memory");
             const uint32_t endy = dy + M;                // biased end of the sequence
             for (uint32_t s_i = 0; s_i < nsub && !gave_up; ++s_i) {
