@@ -282,6 +282,64 @@ def test_segmented_pipeline_mixed_batch():
     assert nerr >= 2
 
 
+def test_segmented_pipeline_grouped_mixed_batch():
+    """Calls of 32 jobs and more take the pipeline's last two stages in groups (capi.hip: seg_groups — the records stage of the next
+    quarter of the jobs, by sequences, under the resolve stage of the one before, on streams of the library's own).  The mixed
+    batch twice over, so that every group holds jobs the pipeline finishes, jobs it fails (damaged blocks, capacity, limit) and jobs
+    it never takes (prefix, existing output, below the window): statuses and bytes as the oracle's, whatever group a job fell into."""
+    rng = np.random.default_rng(78)
+    items, exp = _seg_mixed_items(rng)
+    items, exp = items * 2, exp * 2
+    assert len(items) >= 32
+    res = gpu_decompress(items)
+    for i, ((rc, out), (erc, eout)) in enumerate(zip(res, exp)):
+        assert rc == erc, (i, rc, erc)
+        if rc == 0:
+            assert out == eout, i
+
+
+def test_segmented_pipeline_grouped_beside_application_streams():
+    """The grouped call on a stream of the application's while other application streams are busy (HIP runs a handful of hardware
+    queues: the library's resolve streams must not depend on having one to themselves for correctness), twice in a row without a
+    synchronisation in between (the second call's scratch and events reuse the first's)."""
+    import torch
+    from rust_lz_fear_amd import device
+    mib = 1 << 20
+    base = [synth.silesia_mix(k * 4 * mib, k * 4 * mib + mib).tobytes() for k in (0, 17, 29, 47)] + [synth.gen_records(5, mib).tobytes(), synth.gen_log(7, mib).tobytes()]
+    pairs = [(d, c) for d, (rc, c) in ((d, o.compress2(d)) for d in base) if rc == 0]
+    n = len(pairs) * 16
+    assert 32 <= n <= 256
+    blob = b"".join(c for _, c in pairs)
+    d_in = torch.frombuffer(bytearray(blob), dtype=torch.uint8).cuda()
+    offs = np.cumsum([0] + [len(c) for _, c in pairs])
+    d_out = torch.zeros(n * mib, dtype=torch.uint8, device="cuda")
+    dj = np.zeros(n, dtype=device.DJOB)
+    for k in range(n):
+        i = k % len(pairs)
+        dj["input"][k] = d_in.data_ptr() + int(offs[i]); dj["input_len"][k] = len(pairs[i][1])
+        dj["out"][k] = d_out.data_ptr() + k * mib; dj["out_cap"][k] = mib; dj["output_limit"][k] = mib
+    d_dj = device.to_device(dj, "cuda")
+    d_res = torch.zeros(n * 16, dtype=torch.uint8, device="cuda")
+    mine, busy1, busy2 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    a = torch.randn(2048, 2048, device="cuda")
+    torch.cuda.synchronize()
+    with torch.cuda.stream(busy1):
+        for _ in range(20): a1 = a @ a
+    with torch.cuda.stream(busy2):
+        for _ in range(20): a2 = a @ a
+    with torch.cuda.stream(mine):
+        device.decompress_batch(d_dj, d_res, n)
+        d_out.zero_(); d_res.zero_()
+        device.decompress_batch(d_dj, d_res, n)
+    torch.cuda.synchronize()
+    assert "segmented" in ffi.lib().lzf_last_decompress_launch().decode()
+    r = device.results_to_host(d_res, n)
+    for k in range(n):
+        d = pairs[k % len(pairs)][0]
+        assert r["status"][k] == ffi.OK and int(r["out_len"][k]) == len(d), k
+        assert bytes(d_out[k * mib:k * mib + len(d)].cpu().numpy()) == d, k
+
+
 @pytest.mark.parametrize("seed,nseq", [(41, 30000), (42, 60000), (43, 120000)])
 def test_segmented_pipeline_every_copy_class(seed, nseq):
     """Handcrafted streams that hit every copy path of the resolver (lz4_decompress_seg.hip): the four two-ended sizes with and
