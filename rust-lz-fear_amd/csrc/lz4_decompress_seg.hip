@@ -510,6 +510,16 @@ __global__ __launch_bounds__(64) void lzf_seg_seam_kernel(seg_ctx c) {
                             if (p != e_true && ((wbits[rbit >> 5] >> (rbit & 31u)) & 1u)) { mg = 1; break; }
                             patch[np++] = (uint16_t)(p - ostart);
                             uint32_t nx;
+                            // the common token — lengths with at most one extension byte, everything staged, not the input's end — from
+                            // one unaligned LDS word (+ one byte): the position token_next_gen returns, at a quarter of its instructions
+                            {
+                                uint32_t w;
+                                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(w) : "v"(wb_a + (p - ws)) : "memory");
+                                const uint32_t L0 = (w >> 4) & 15u, M0 = w & 15u, b1 = (w >> 8) & 255u;
+                                const uint32_t q2 = p + 1u + (L0 == 15u ? 1u + 15u + b1 : L0);       // the offset's position
+                                if (!(L0 == 15u && b1 == 255u) && q2 + 3u <= len && q2 - ws + 3u <= kWin + 128u &&
+                                    !(M0 == 15u && wbytes[q2 + 2u - ws] == 255u)) { p = q2 + 2u + (M0 == 15u ? 1u : 0u); continue; }
+                            }
                             if (!token_next_gen(len, p, nx, rd8, rdb)) { err = 1; break; }
                             p = nx;
                         }
@@ -591,6 +601,8 @@ __device__ __forceinline__ uint32_t tile_enumerate(const seg_ctx& c, uint32_t j,
 }
 struct Tok { uint32_t L, M, off, src; bool err; };
 // decompress.rs:61-74 for the token at p (p < len): lengths, offset, where its literals are.  M = 0: the last sequence.
+// WANT_OFF = false: the lengths alone (the tile sums do not look at the offset).
+template <bool WANT_OFF = true>
 __device__ __forceinline__ Tok tile_decode(const TileCtx& t, uint32_t p) {
     Tok k; k.err = false; k.M = 0; k.off = 0;
     const uint32_t len = t.len;
@@ -611,7 +623,7 @@ __device__ __forceinline__ Tok tile_decode(const TileCtx& t, uint32_t p) {
     if (len - q < L) { k.err = true; return k; }           // :67 read_exact
     q += L;
     if (len - q < 2u) return k;                            // :70 read_u16 fails: last literals, no match
-    k.off = tile_rdb(t, q) | (tile_rdb(t, q + 1u) << 8);
+    if (WANT_OFF) k.off = tile_rdb(t, q) | (tile_rdb(t, q + 1u) << 8);
     q += 2u;
     uint32_t M = tok & 15u;
     if (M == 15u) { if (!read_lsic_tail(q, len, M, rd8, rdb) || M > kLenClamp) k.err = true; }
@@ -637,7 +649,7 @@ __global__ __launch_bounds__(64) void lzf_seg_tilesum_kernel(seg_ctx c) {
         uint32_t sum = 0; bool err = false;
         for (uint32_t i0 = 0; i0 < n; i0 += 64u) {
             if (i0 + lane < n) {
-                const Tok k = tile_decode(tc, tc.tstart + list[i0 + lane]);
+                const Tok k = tile_decode<false>(tc, tc.tstart + list[i0 + lane]);
                 err = err || k.err;
                 sum += k.L + k.M;                          // (each <= 2^26 + 4, at most 11 per lane)
             }
@@ -661,18 +673,25 @@ __global__ __launch_bounds__(64) void lzf_seg_scan_kernel(seg_ctx c) {
     LZF_GLOBAL uint32_t* const TT = (LZF_GLOBAL uint32_t*)c.tile_tok + (size_t)j * c.maxtile;
     LZF_GLOBAL uint32_t* const TO = (LZF_GLOBAL uint32_t*)c.tile_out + (size_t)j * c.maxtile;
     uint64_t ctok = 0, cout = 0;
-    for (uint32_t t0 = 0; t0 < sj.ntile; t0 += 64u) {
-        const uint32_t t = t0 + lane;
-        const uint32_t a = t < sj.ntile ? TT[t] : 0u, b = t < sj.ntile ? TO[t] : 0u;
-        // 64-bit running sums (a job whose output does not fit 31 bits is not ours)
-        const uint32_t ia = wave_scan_add(a);
-        uint32_t blo = b & 0xFFFFu, bhi = b >> 16;
-        const uint32_t ilo = wave_scan_add(blo), ihi = wave_scan_add(bhi);
-        const uint64_t ib = (uint64_t)ilo + ((uint64_t)ihi << 16);
-        const uint64_t eo = cout + ib - b;
-        if (t < sj.ntile) { TT[t] = (uint32_t)(ctok + ia - a); TO[t] = eo > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)eo; }
-        ctok += __builtin_amdgcn_readlane(ia, 63);
-        cout += (uint64_t)__builtin_amdgcn_readlane(ilo, 63) + ((uint64_t)__builtin_amdgcn_readlane(ihi, 63) << 16);
+    // (eight steps' loads in flight at once: with one step per round trip to HBM the kernel was 33 dependent loads long, 75 us)
+    for (uint32_t t8 = 0; t8 < sj.ntile; t8 += 512u) {
+        uint32_t av[8], bv[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) { const uint32_t t = t8 + 64u * k + lane; av[k] = t < sj.ntile ? TT[t] : 0u; bv[k] = t < sj.ntile ? TO[t] : 0u; }
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) {
+            const uint32_t t = t8 + 64u * k + lane;
+            const uint32_t a = av[k], b = bv[k];
+            // 64-bit running sums (a job whose output does not fit 31 bits is not ours)
+            const uint32_t ia = wave_scan_add(a);
+            uint32_t blo = b & 0xFFFFu, bhi = b >> 16;
+            const uint32_t ilo = wave_scan_add(blo), ihi = wave_scan_add(bhi);
+            const uint64_t ib = (uint64_t)ilo + ((uint64_t)ihi << 16);
+            const uint64_t eo = cout + ib - b;
+            if (t < sj.ntile) { TT[t] = (uint32_t)(ctok + ia - a); TO[t] = eo > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)eo; }
+            ctok += __builtin_amdgcn_readlane(ia, 63);
+            cout += (uint64_t)__builtin_amdgcn_readlane(ilo, 63) + ((uint64_t)__builtin_amdgcn_readlane(ihi, 63) << 16);
+        }
     }
     if (lane == 0u) {
         const uint64_t cap = job.out_cap > kMaxPosB ? kMaxPosB : job.out_cap;
