@@ -212,7 +212,7 @@ int seg_launch_front(const lzf::seg_ctx& c, uint32_t upto, hipStream_t st) {
     if (upto >= 6) LAUNCH(lzf::lzf_seg_records_kernel, dim3(seg_grid(tg_tile, n, c.maxtile), n), dim3(64), 0, st, c);
     return LZF_OK;
 }
-// the records stage (and the resolve stage's workgroup order) of the group the context names, on their own
+// the records stage of the group the context names, on its own
 int seg_launch_records(const lzf::seg_ctx& c, hipStream_t st) {
     const uint32_t n = c.g_n;
     uint32_t tg_tile = 2048u * c.n_cu;
@@ -223,7 +223,6 @@ int seg_launch_records(const lzf::seg_ctx& c, hipStream_t st) {
 #ifdef LZF_ANALYSIS      // LZF_SEG_REC_PAD = bytes of unused LDS per workgroup of a grouped call's records stage (fewer of them resident under the resolve stages: A/B)
     { static const uint32_t e = [] { const char* v = getenv("LZF_SEG_REC_PAD"); return v ? (uint32_t)atol(v) : 0u; }(); pad = e; }
 #endif
-    if (c.order) LAUNCH(lzf::lzf_seg_order_kernel, dim3(1), dim3(1024), 0, st, c);
     LAUNCH(lzf::lzf_seg_records_kernel, dim3(seg_grid(tg_tile, n, c.maxtile), n), dim3(64), pad, st, c);
     return LZF_OK;
 }
@@ -306,12 +305,17 @@ int seg_enqueue_groups(SegScratch& s, const SegGroups& g, SegLanes& L, hipStream
     int rc = seg_launch_prep(c, st);
     if (rc == LZF_OK) rc = seg_launch_front(c, 5u, st);         // plan .. scan over the whole call
     if (rc != LZF_OK) return rc;
-    LAUNCH(lzf::lzf_seg_rank_kernel, dim3(1), dim3(1024), 0, st, c, s.est);      // s.est: the jobs by sequences, most first
+    static_assert(kSegMaxGroups == 4, "lzf_seg_rank_kernel takes the group sizes as a uint4");
+    LAUNCH(lzf::lzf_seg_rank_kernel, dim3(1), dim3(1024), 0, st, c, s.est, make_uint4(g.size[0], g.n > 1u ? g.size[1] : 0u, g.n > 2u ? g.size[2] : 0u, g.n > 3u ? g.size[3] : 0u));      // s.est: the jobs by sequences, most first; + every group's workgroup order
     c.by_len = s.est; c.grouped = 1u; c.res_prio = 1u;
 #ifdef LZF_ANALYSIS      // LZF_SEG_PRIO=0: the resolve stage at the default issue priority (A/B)
     { static const int pr = [] { const char* e = getenv("LZF_SEG_PRIO"); return e ? atoi(e) : 1; }(); c.res_prio = pr ? 1u : 0u; }
 #endif
     uint32_t off = 0, forked = 0;
+    uint32_t pause_ticks = 1000u;                                // 10 us of the 100 MHz clock (5 .. 80 us measured alike)
+#ifdef LZF_ANALYSIS      // LZF_SEG_PAUSE_US: the pause between a group's records stage and the next (A/B; 0 = none)
+    { static const int us = [] { const char* e = getenv("LZF_SEG_PAUSE_US"); return e ? atoi(e) : -1; }(); if (us >= 0) pause_ticks = (uint32_t)us * 100u; }
+#endif
     for (uint32_t k = 0; k < g.n && rc == LZF_OK; ++k) {
         c.g_off = off; c.g_n = g.size[k]; off += g.size[k];
         rc = seg_launch_records(c, st);
@@ -320,6 +324,7 @@ int seg_enqueue_groups(SegScratch& s, const SegGroups& g, SegLanes& L, hipStream
             if (hipEventRecord(L.front[k], st) != hipSuccess || hipStreamWaitEvent(L.s[k], L.front[k], 0) != hipSuccess) { (void)hipGetLastError(); rc = LZF_E_HIP; break; }
             rc = seg_launch_resolve(c, L.s[k]);
             ++forked;                                            // (whatever was enqueued on the lane is joined below)
+            if (pause_ticks) LAUNCH(lzf::lzf_seg_pause_kernel, dim3(1), dim3(64), 0, st, pause_ticks);      // the resolve stage's workgroups first, then the next records stage
             if (hipEventRecord(L.done[k], L.s[k]) != hipSuccess) { (void)hipGetLastError(); --forked; if (rc == LZF_OK) rc = LZF_E_HIP; if (hipStreamSynchronize(L.s[k]) != hipSuccess) (void)hipGetLastError(); }
         } else {
             rc = seg_launch_resolve(c, st);                      // the last group: on the caller's stream

@@ -113,7 +113,8 @@ __global__ void lzf_seg_plan_kernel(seg_ctx c);
 // sequences and dealt out in rows of n_cu, every other row reversed, so that the blocks that share a CU (workgroups k, k + n_cu,
 // k + 2 n_cu ... land on the same CU) are a slow one with fast ones: the launch ends with its slowest CU
 __global__ void lzf_seg_order_kernel(seg_ctx c);
-__global__ void lzf_seg_rank_kernel(seg_ctx c, uint32_t* __restrict__ by_tok);
+__global__ void lzf_seg_pause_kernel(uint32_t ticks);
+__global__ void lzf_seg_rank_kernel(seg_ctx c, uint32_t* __restrict__ by_tok, uint4 group_sizes);
 // the same batches: grid row -> job for the chunk / tile stages, longest input first (a launch ends with its last rows)
 __global__ void lzf_seg_by_len_kernel(seg_ctx c);
 __global__ void lzf_seg_parse_kernel(seg_ctx c);
