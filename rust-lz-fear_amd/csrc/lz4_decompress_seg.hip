@@ -1381,6 +1381,7 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
             if (gave_up) break;
         }
 #ifdef LZF_SEG_TIME
+        if (lane == 0u) flag_set(2, (uint32_t)(tm_wait >> 10));      // (to the stager, which writes the job's result: results[].reserved = this | total << 16, in units of 2^10 / 2^14 cycles)
         if (lane == 0u) { reinterpret_cast<uint16_t*>(&c.st[j].pad)[0] = (uint16_t)(n_rounds >> 4);
             c.st[j].pad2 = (unsigned long long)(uint16_t)(tm_wait >> 14) | ((unsigned long long)(uint16_t)(tm_setup >> 14) << 16) | ((unsigned long long)(uint16_t)(tm_asm >> 14) << 32) | ((unsigned long long)(uint16_t)(tm_slow >> 14) << 48); }
 #endif
@@ -1437,7 +1438,7 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
             }
         };
 #ifdef LZF_SEG_TIME
-        long long tm_swait = 0;
+        long long tm_swait = 0, tm_fill = 0, tm_old = 0;
         bool gave_up = false;
         auto wait_resolved = [&](uint32_t tt) { const long long t0 = clock64(); if (tt && !gave_up && !flag_wait_above(1, tt - 1u)) gave_up = true; tm_swait += clock64() - t0; };
 #else
@@ -1451,6 +1452,13 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
 #endif
         if (n) { rA = recs[lane < n ? lane : n - 1u]; rB = recs[64u + lane < n ? 64u + lane : n - 1u]; }
         uint32_t prev_end = rb;                          // biased end of the previous sequence
+        // Sources older than the ring (class 7) of the NEXT batch's first sub-batch, loaded while this batch is staged: with the small
+        // rings every sub-batch of a text block has some (offsets beyond ~20 KiB), and their round trip to HBM sat in the stager's
+        // critical path — at four blocks per CU the stager spent 47 % of the block's time there and the resolver a third of its time
+        // waiting for tickets (profiles/r05_seg_groups.txt, section 7).  Per lane: a match of 4..32 bytes whose source is below `safe`.
+        uint64_t ov0 = 0, ov1 = 0, ov2 = 0, ov3 = 0;
+        uint32_t o_for = kNone;                          // the batch (its first record) the registers were loaded for
+        bool o_have = false;
         for (uint32_t i0 = 0; i0 < n && !gave_up; i0 += 64u) {
 #ifdef LZF_ANALYSIS      // LZF_SEG_FORCE=stager: the stager of every odd job gives up at its third batch
             if (c.dbg_force == 1u && (j & 1u) && i0 >= 128u) { gave_up = true; if (lane == 0u) flag_set(3, 1u); break; }
@@ -1516,10 +1524,34 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
 #if defined(LZF_SEG_DBG_SKIP) && LZF_SEG_DBG_SKIP == 3
                     fp = (oe + 15u) & ~15u;
 #endif
+#ifdef LZF_SEG_TIME
+                    const long long tf0 = clock64();
+#endif
                     prefetch_commit();
                     fill_to((oe + 15u) & ~15u);
+#ifdef LZF_SEG_TIME
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                    tm_fill += clock64() - tf0;
+#endif
                     prefetch_issue((oe + 15u) & ~15u);
-                    const bool old = sub == s_i && cls == 7u;
+                    bool old = sub == s_i && cls == 7u;
+#ifdef LZF_SEG_TIME
+                    const long long to0 = clock64();
+#endif
+                    {   // the lanes whose bytes came early (two-ended pieces, as put_small_glb stores them)
+                        const bool early = old && s_i == 0u && o_for == i0 && o_have;
+                        if (__ballot(early)) {
+                            if (early) {
+                                const uint32_t d = ring_a + (dy & kMask);
+                                if (M >= 8u) {
+                                    lds_st64(d, ov0);
+                                    if (M > 16u) { lds_st64(d + 8u, ov1); lds_st64(d + M - 16u, ov2); }
+                                    lds_st64(d + M - 8u, ov3);
+                                } else { lds_st32(d, (uint32_t)ov0); lds_st32(d + M - 4u, (uint32_t)ov3); }
+                            }
+                            old = old && !early;
+                        }
+                    }
                     if (__ballot(old)) {
                         // (a rare path: its operands pass through an empty asm statement, or its predicates are computed per batch)
                         uint32_t M_o = M, off_o = off, dy_o = dy;
@@ -1536,14 +1568,16 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                             const uint32_t q = (uint32_t)__builtin_ctzll(m);
                             const uint32_t qM = __builtin_amdgcn_readlane(M, q), qs = __builtin_amdgcn_readlane(sy, q), qd = __builtin_amdgcn_readlane(dy, q);
                             const uint32_t qo = __builtin_amdgcn_readlane(off, q);
-                            if (lane == q) {
-                                for (uint32_t i = 0; i < qM; ++i) {
-                                    const uint32_t y = qs + (qo < qM ? i % qo : i);
-                                    ring[(qd + i) & kMask] = y < fl ? (uint8_t)outb[y] : ring[y & kMask];
-                                }
+                            // (all lanes, a byte each per step: the source lies in front of the destination, so no byte read here is one written here)
+                            for (uint32_t i = lane; i < qM; i += kWave) {
+                                const uint32_t y = qs + (qo < qM ? i % qo : i);
+                                ring[(qd + i) & kMask] = y < fl ? (uint8_t)outb[y] : ring[y & kMask];
                             }
                         }
                     }
+#ifdef LZF_SEG_TIME
+                    { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); tm_old += clock64() - to0; }
+#endif
                 }
                 const uint32_t eg = oe & ~15u;
                 { const uint32_t k3 = ticket % 3u; if (k3 == 0u) endq0 = eg; else if (k3 == 1u) endq1 = eg; else endq2 = eg; }
@@ -1551,6 +1585,22 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                 ++ticket;
                 if (lane == 0u) flag_set(0, ticket);
                 prev_end = oe;
+            }
+            // ---- the next batch's old sources, early (its records are in rA)
+            o_for = kNone; o_have = false;
+            if (i0 + 64u < n && !gave_up) {
+                const u32x4 q = rA;
+                const uint32_t nbn = n - (i0 + 64u) < 64u ? n - (i0 + 64u) : 64u;
+                const uint32_t Mn = q[0], dyn = q[1], offn = q[3];
+                const uint32_t syn = dyn - offn, din = dyn & kMask;
+                o_have = lane < nbn && (q[2] >> 24) == 7u && (q[2] & 0xFFu) == 0u && Mn >= 4u && Mn <= 32u && offn >= Mn &&
+                         din + Mn <= (uint32_t)R && syn + Mn <= safe && syn + Mn <= fl;
+                o_for = i0 + 64u;
+                if (o_have) {
+                    cgu8* g = outb + syn;
+                    if (Mn >= 8u) { ov0 = ld8(g); ov3 = ld8(g + Mn - 8u); if (Mn > 16u) { ov1 = ld8(g + 8u); ov2 = ld8(g + Mn - 16u); } }
+                    else { ov0 = ld4(g); ov3 = ld4(g + Mn - 4u); }
+                }
             }
         }
         wait_resolved(ticket);
@@ -1569,7 +1619,13 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
         if (lane == 0u) {
             c.results[j].out_len = total;
             c.results[j].status = LZF_OK;
+#ifdef LZF_SEG_TIME
+            // resolver's wait for tickets | stager: fills | stager: sources older than the ring | total — a byte each, in 2^17 cycles
+            { auto b8 = [](long long v) -> uint32_t { const long long x = v >> 17; return x > 255 ? 255u : (uint32_t)x; };
+              c.results[j].reserved = b8((long long)flag_get(2) << 10) | (b8(tm_fill) << 8) | (b8(tm_old) << 16) | (b8(clock64() - t_start) << 24); }
+#else
             c.results[j].reserved = (uint32_t)((clock64() - t_start) >> 10);
+#endif
             c.st[j].done = 1u;
         }
     }

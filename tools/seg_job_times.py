@@ -21,6 +21,13 @@ d_dj = device.to_device(dj, 'cuda'); d_res2 = torch.zeros(m * 16, dtype=torch.ui
 for _ in range(3):
     device.decompress_batch(d_dj, d_res2, m); torch.cuda.synchronize()
 r2 = device.results_to_host(d_res2, m)
+if os.environ.get("LZF_TIME_SPLIT"):      # an LZF_SEG_TIME build: reserved = resolver's wait for tickets | stager fills | stager old sources | total, a byte each, 2^17 cycles
+    rv = r2['reserved'].astype(np.int64)
+    wait, fill, old, tot = [((rv >> sh) & 255) * 131 for sh in (0, 8, 16, 24)]      # k-cycles
+    o = np.argsort(-tot)
+    print("resolve stage, k-cycles per job (slowest 10 of %d; means: total %.0f, resolver waiting for tickets %.0f, stager in fills %.0f, stager on sources older than the ring %.0f)" % (m, tot.mean(), wait.mean(), fill.mean(), old.mean()))
+    for k in o[:10]: print(f"  job {int(k):4d} block {int(idx[k]):3d}  total {int(tot[k]):6d}  resolver waiting {int(wait[k]):6d}  stager: fills {int(fill[k]):6d}  old sources {int(old[k]):6d}")
+    sys.exit(0)
 t = r2['reserved'][:len(ok)].astype(np.int64)
 o = np.argsort(-t)
 print("block  in_len  resolve_kcycles   (sorted by resolve time; %d blocks, %d copies)" % (len(ok), copies))
