@@ -136,7 +136,7 @@ bool seg_alloc(SegScratch& s, const lzf_decompress_job* d_jobs, lzf_job_result* 
     lzf::seg_ctx& c = s.ctx;
     c.jobs = d_jobs; c.results = d_results; c.n_jobs = n;
 #ifdef LZF_ANALYSIS      // LZF_SEG_FORCE=noscratch | stager | resolver: the pipeline's fall-backs, forced (tests/test_gpu_parity.py)
-    { static const uint32_t force = [] { const char* e = getenv("LZF_SEG_FORCE"); return !e ? 0u : !strcmp(e, "stager") ? 1u : !strcmp(e, "resolver") ? 2u : !strcmp(e, "noscratch") ? 3u : 0u; }();
+    { static const uint32_t force = [] { const char* e = getenv("LZF_SEG_FORCE"); return !e ? 0u : !strcmp(e, "stager") ? 1u : !strcmp(e, "resolver") ? 2u : !strcmp(e, "noscratch") ? 3u : !strcmp(e, "swait") ? 8u : 0u; }();
       if (force == 3u) return false;
       c.dbg_force = force; }
 #endif

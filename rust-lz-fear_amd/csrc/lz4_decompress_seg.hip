@@ -1622,7 +1622,7 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
 #ifdef LZF_SEG_TIME
             // resolver's wait for tickets | stager: fills | stager: sources older than the ring | total — a byte each, in 2^17 cycles
             { auto b8 = [](long long v) -> uint32_t { const long long x = v >> 17; return x > 255 ? 255u : (uint32_t)x; };
-              c.results[j].reserved = b8((long long)flag_get(2) << 10) | (b8(tm_fill) << 8) | (b8(tm_old) << 16) | (b8(clock64() - t_start) << 24); }
+              c.results[j].reserved = b8((long long)flag_get(2) << 10) | (b8(c.dbg_force == 8u ? tm_swait : tm_fill) << 8) | (b8(tm_old) << 16) | (b8(clock64() - t_start) << 24); }
 #else
             c.results[j].reserved = (uint32_t)((clock64() - t_start) >> 10);
 #endif
