@@ -1003,10 +1003,6 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
         uint32_t t = 0, staged = 0;                       // tickets resolved; tickets known to be staged (the flag as last read)
         // the records come straight from HBM, two batches ahead (the only loads of this wave: they return in order and in time)
         u32x4 rA = u32x4{0, 0, 0, 0}, rB = u32x4{0, 0, 0, 0};
-#ifdef LZF_SEG_DEEP
-        u32x4 rC = u32x4{0, 0, 0, 0}, rD = u32x4{0, 0, 0, 0};
-        if (n) { rC = recs[128u + lane < n ? 128u + lane : n - 1u]; rD = recs[192u + lane < n ? 192u + lane : n - 1u]; }
-#endif
         if (n) { rA = recs[lane < n ? lane : n - 1u]; rB = recs[64u + lane < n ? 64u + lane : n - 1u]; }
         auto wait_staged = [&](uint32_t tt) -> bool {    // ticket tt published?  (one read of the flag usually covers several tickets)
             if (staged > tt) return true;
@@ -1022,12 +1018,7 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
             const u32x4 r = rA;
             asm volatile("" ::: "memory");
             rA = rB;
-#ifdef LZF_SEG_DEEP
-            rB = rC; rC = rD;
-            { const uint32_t ix = i0 + 256u + lane; rD = recs[ix < n ? ix : n - 1u]; }
-#else
             { const uint32_t ix = i0 + 128u + lane; rB = recs[ix < n ? ix : n - 1u]; }
-#endif
             asm volatile("" ::: "memory");
             RT(tm_setup);
             if (!wait_staged(t)) break;
@@ -1446,10 +1437,6 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
         auto wait_resolved = [&](uint32_t tt) { if (tt && !gave_up && !flag_wait_above(1, tt - 1u)) gave_up = true; };
 #endif
         u32x4 rA = u32x4{0, 0, 0, 0}, rB = u32x4{0, 0, 0, 0};
-#ifdef LZF_SEG_DEEP
-        u32x4 rC = u32x4{0, 0, 0, 0}, rD = u32x4{0, 0, 0, 0};
-        if (n) { rC = recs[128u + lane < n ? 128u + lane : n - 1u]; rD = recs[192u + lane < n ? 192u + lane : n - 1u]; }
-#endif
         if (n) { rA = recs[lane < n ? lane : n - 1u]; rB = recs[64u + lane < n ? 64u + lane : n - 1u]; }
         uint32_t prev_end = rb;                          // biased end of the previous sequence
         // Sources older than the ring (class 7) of the NEXT batch's first sub-batch, loaded while this batch is staged: with the small
@@ -1470,12 +1457,7 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
             const uint32_t nsub = __builtin_amdgcn_readlane(r[2] & 0xFFu, (nb - 1u) & 63u) + 1u;
             asm volatile("" ::: "memory");
             rA = rB;
-#ifdef LZF_SEG_DEEP
-            rB = rC; rC = rD;
-            { const uint32_t ix = i0 + 256u + lane; rD = recs[ix < n ? ix : n - 1u]; }
-#else
             { const uint32_t ix = i0 + 128u + lane; rB = recs[ix < n ? ix : n - 1u]; }
-#endif
             asm volatile("" ::: "memory");
             const uint32_t endy = dy + M;                // biased end of the sequence
             for (uint32_t s_i = 0; s_i < nsub && !gave_up; ++s_i) {
