@@ -927,13 +927,14 @@ __global__ __launch_bounds__(1024) void lzf_seg_order_kernel(seg_ctx c) {
 // their own, two batches ahead of their use.
 // Tickets = sub-batches in stream order: the stager publishes ticket t with ctl[0] = t + 1 after its LDS writes, the
 // resolver answers ctl[1] = t + 1 after its own; LDS executes one wave's accesses in order, so a flag is never seen before
-// the data.  The stager runs at most NS tickets ahead (and loads the granules behind its fill pointer one sub-batch early);
+// the data.  The stager runs at most NT tickets and NS sub-batch spans of output ahead (and loads the granules behind its fill pointer one sub-batch early);
 // the records stage classed the sources with that fetch-ahead in mind.
 template <int R>
 __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
     constexpr uint32_t kMask = (uint32_t)R - 1u;
     constexpr uint32_t kSpan = (uint32_t)R / 8u;       // output bytes one sub-batch may produce
-    constexpr uint32_t NS = 3;                         // tickets the stager may be ahead
+    constexpr uint32_t NS = 3;                         // sub-batch spans of output the stager may be ahead (what the records stage classed the sources for)
+    constexpr uint32_t NT = 32;                        // tickets it may be ahead (a text block's sub-batch is a batch, ~1 KiB: three were 6 us of slack, less than HBM answers in under load)
     // (the ring starts 64 bytes into the workgroup's LDS: an address 32 bytes in front of a ring position is never negative)
     __shared__ __attribute__((aligned(16))) uint8_t lds_all[64 + R];
     uint8_t* const ring = lds_all + 64;
@@ -1381,8 +1382,8 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
         // ================================================= STAGER =================================================
         uint32_t fp = 0, fl = rb, safe = 0;              // filled up to (granule), flushed up to, own stores visible below
         uint32_t ticket = 0;                             // tickets published
-        static_assert(NS == 3, "the ends of the tickets in flight live in three scalars");
-        uint32_t endq0 = rb, endq1 = rb, endq2 = rb;     // biased end (rounded down to a granule) of the published tickets, by ticket % 3
+        static_assert(NT <= 32, "the ends of the tickets in flight live in the lanes of one register");
+        uint32_t endv = rb;                              // lane t % 64: biased end (rounded down to a granule) of published ticket t
         uint32_t flushed_t = 0;                          // tickets whose bytes are in HBM
         auto flush_range = [&](uint32_t y0, uint32_t y1) {
             if (y1 <= y0) return;
@@ -1422,8 +1423,7 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
         // write what the resolver has finished to HBM (whole granules), in ticket order
         auto flush_resolved = [&](uint32_t upto_t) {
             while (flushed_t < upto_t) {
-                const uint32_t k3 = flushed_t % 3u;
-                const uint32_t e = k3 == 0u ? endq0 : k3 == 1u ? endq1 : endq2;
+                const uint32_t e = __builtin_amdgcn_readlane(endv, flushed_t & 63u);
                 if (e > fl) { flush_range(fl, e); fl = e; }
                 ++flushed_t;
             }
@@ -1498,11 +1498,30 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
                     }
                 } else {
                     // ---- sub-batch: the ring filled, the sources older than the ring moved in
-                    if (ticket >= NS) wait_resolved(ticket - NS + 1u);
+                    // Room: fewer than NT tickets unresolved, and the ring filled no further than two spans beyond the end of the oldest
+                    // unresolved ticket r (with the 3 KiB the early loads may add: within the fetch-ahead the records stage assumed,
+                    // oe_r + 3 spans + 64 — with three tickets in flight that held by itself, a sub-batch being at most a span).
+                    uint32_t rs = 0;
+                    {
+                        const uint32_t need = (oe + 15u) & ~15u;
+#ifdef LZF_SEG_TIME
+                        const long long t0 = clock64();
+#endif
+                        for (uint32_t spin = 0; !gave_up; ++spin) {
+                            rs = flag_get(1);
+                            const uint32_t er = rs < ticket ? __builtin_amdgcn_readlane(endv, rs & 63u) : need;
+                            if (ticket - rs < NT && need <= er + 2u * kSpan + 16u) break;
+                            if ((spin & 63u) == 63u && (flag_get(3) != 0u || spin > (1u << 22))) { if (lane == 0u) flag_set(3, 1u); gave_up = true; break; }
+                            __builtin_amdgcn_s_sleep(1);
+                        }
+#ifdef LZF_SEG_TIME
+                        tm_swait += clock64() - t0;
+#endif
+                    }
 #if defined(LZF_SEG_DBG_SKIP) && LZF_SEG_DBG_SKIP == 3      // analysis: a stager that moves no bytes (what the resolver costs on its own)
                     if (false)
 #endif
-                    { const uint32_t rs = flag_get(1); flush_resolved(rs < ticket ? rs : ticket); }
+                    flush_resolved(rs < ticket ? rs : ticket);
 #if defined(LZF_SEG_DBG_SKIP) && LZF_SEG_DBG_SKIP == 3
                     fp = (oe + 15u) & ~15u;
 #endif
@@ -1562,7 +1581,7 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
 #endif
                 }
                 const uint32_t eg = oe & ~15u;
-                { const uint32_t k3 = ticket % 3u; if (k3 == 0u) endq0 = eg; else if (k3 == 1u) endq1 = eg; else endq2 = eg; }
+                if (lane == (ticket & 63u)) endv = eg;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the ring and the slot written; loads and stores to HBM stay in flight
                 ++ticket;
                 if (lane == 0u) flag_set(0, ticket);
