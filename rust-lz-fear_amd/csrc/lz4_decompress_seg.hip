@@ -1422,10 +1422,10 @@ __global__ __launch_bounds__(128) void lzf_seg_resolve_pair_kernel(seg_ctx c) {
         };
         // write what the resolver has finished to HBM (whole granules), in ticket order
         auto flush_resolved = [&](uint32_t upto_t) {
-            while (flushed_t < upto_t) {
-                const uint32_t e = __builtin_amdgcn_readlane(endv, flushed_t & 63u);
+            if (flushed_t < upto_t) {                    // (the ends only grow: everything up to the last resolved ticket's in one pass)
+                const uint32_t e = __builtin_amdgcn_readlane(endv, (upto_t - 1u) & 63u);
                 if (e > fl) { flush_range(fl, e); fl = e; }
-                ++flushed_t;
+                flushed_t = upto_t;
             }
         };
 #ifdef LZF_SEG_TIME
