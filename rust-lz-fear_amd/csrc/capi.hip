@@ -280,9 +280,17 @@ struct SegLanes {
     bool ok = false;
 };
 SegLanes* seg_lanes() {
-    static SegLanes* lanes = [] {
+    // (per device: a stream belongs to the device that was current when it was made — one process per GPU is the rule, but a process
+    //  that moves between devices must not get another device's streams)
+    constexpr int kMaxDev = 64;
+    static std::mutex mu;
+    static SegLanes* by_dev[kMaxDev] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) { (void)hipGetLastError(); return nullptr; }
+    std::lock_guard<std::mutex> lk(mu);
+    if (!by_dev[dev]) {
         SegLanes* L = new SegLanes();
-        // High-priority streams: the runtime keeps a pool of hardware queues per priority (four each by default), so these three do not
+        // High-priority streams: the runtime keeps a pool of hardware queues PER PRIORITY (four each by default), so these three do not
         // end up sharing a queue with the application's own streams — a resolve stage queued behind the caller's next records stage
         // would serialise the call (measured: 49 blocks 13.4 ms instead of 8.0 with one application side stream alive) — and the
         // resolve stage, the chain of the call, is dispatched ahead of the throughput kernels.
@@ -295,9 +303,9 @@ SegLanes* seg_lanes() {
                  hipEventCreateWithFlags(&L->done[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) (void)hipGetLastError();
         L->ok = ok;
-        return L;
-    }();
-    return lanes->ok ? lanes : nullptr;
+        by_dev[dev] = L;
+    }
+    return by_dev[dev]->ok ? by_dev[dev] : nullptr;
 }
 int seg_enqueue_groups(SegScratch& s, const SegGroups& g, SegLanes& L, hipStream_t st) {
     lzf::seg_ctx c = s.ctx;
