@@ -19,11 +19,11 @@ ROOT = os.path.dirname(PKG_DIR)
 LIB_PATH = os.environ.get("LZF_LIB_PATH") or os.path.join(PKG_DIR, "liblzfear_hip.so")   # override: analysis builds only
 ANALYSIS_LIB_PATH = os.path.join(PKG_DIR, "liblzfear_hip_analysis.so")
 
-PRODUCT_HIP = ["capi.hip", "lz4_decompress_batched.hip", "lz4_decompress_paired.hip", "lz4_decompress_seg.hip", "lz4_compress.hip",
+PRODUCT_HIP = ["capi.hip", "lz4_decompress_batched.hip", "lz4_decompress_paired.hip", "lz4_decompress_seg.hip", "lz4_decompress_fed.hip", "lz4_compress.hip",
                "lz4_compress_compact.hip", "lz4_compress_team.hip", "aux_kernels.hip"]
 ANALYSIS_HIP = ["analysis/lz4_decompress.hip"]
 CXX_SOURCES = ["frame.cpp", "host_staging.cpp"]
-HEADERS = ["kernels.h", "lzf_device.h", "lz4_decompress_batch_phase.inc", "lz4_decompress_parse_phase.inc",
+HEADERS = ["kernels.h", "lzf_device.h", "lz4_decompress_batch_phase.inc", "lz4_decompress_parse_phase.inc", "lz4_decompress_feed_phase.inc",
            "analysis/capi_analysis.inc",
            "lzf_copy_helpers.h", "lzf_parse_helpers.h", "lzf_compress_common.h", "lzf_simt.h", "lz4_compress_team.inc",
            "host_staging.h",

@@ -181,7 +181,7 @@ bool seg_alloc(SegScratch& s, const lzf_decompress_job* d_jobs, lzf_job_result* 
     c.order = (n > c.n_cu && n <= seg_max_jobs()) ? reinterpret_cast<uint32_t*>(b + o_ord) : nullptr;      // (one block per CU: nothing to balance)
     c.by_len = (n >= (c.n_cu + 7u) / 8u && n <= seg_max_jobs()) ? reinterpret_cast<uint32_t*>(b + o_len) : nullptr;       // (MI355X: 32 jobs and more)
     c.rec_by_len = n >= (c.n_cu + 3u) / 4u ? 1u : 0u;                                                                      // (64 and more)
-    c.g_off = 0u; c.g_n = n; c.grouped = 0u; c.res_prio = 0u;
+    c.g_off = 0u; c.g_n = n; c.grouped = 0u; c.res_prio = 0u; c.fed = 0u;
     s.est = reinterpret_cast<uint32_t*>(b + o_est);
     return true;
 }
@@ -367,6 +367,114 @@ int seg_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, 
     return rc;
 }
 
+// ---- the bitmap-fed kernel (lz4_decompress_fed.hip): batches beyond the segmented pipeline's ----------------------------------
+// plan + parse + seam of the segmented pipeline over the whole batch (the token bit map of every block: one bit per compressed
+// byte), then one wavefront per block that lists its tokens from the map and copies — the in-kernel parse of the pair kernel is
+// 13.0 of its 27.8 wave-instructions per sequence, the hop parse 3.8 — then the pair kernel over whatever that left (errors,
+// sizes outside the map's window, a chain that did not verify).
+constexpr auto k_fed32 = lzf::lzf_decompress_fed_kernel<4096, 32, 352>;
+constexpr uint32_t kFedMinInDefault = 1024u;                         // smaller inputs are left to the pair kernel
+inline uint32_t fed_min_in() {
+#ifdef LZF_ANALYSIS      // LZF_FED_MIN_IN: the smallest input the bitmap-fed kernel takes (the variant parity test opens it to every input)
+    static const long v = [] { const char* e = getenv("LZF_FED_MIN_IN"); return e ? atol(e) : -1L; }();
+    if (v >= 0) return (uint32_t)v;
+#endif
+    return kFedMinInDefault;
+}
+constexpr uint64_t kFedMaxScratch = 24ull << 30;                     // bit maps of a call: 1 bit per compressed byte of the largest job x jobs (16 / 14 with the chunks' overlap)
+constexpr uint32_t kFedMaxJobs = 65535u;                             // (the chunk stage's grid has one row per job)
+// Workgroups of the kernel the current device holds at once, COUNTED (lz4_decompress_fed.hip, census mode): the occupancy query
+// does not know the LDS allocation granule (6 912 bytes take 7 680: 21 per CU, the query says 23), and a schedule with more slots
+// than residents runs its surplus slots after the others.  Once per device and process: one launch of ~0.1 ms and a 4-byte copy
+// (the one place a batch call waits for the device).
+uint32_t fed_slots(hipStream_t st) {
+    constexpr int kMaxDev = 64;
+    static std::mutex mu;
+    static uint32_t by_dev[kMaxDev] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) { (void)hipGetLastError(); return 8u * cu_count(); }
+    std::lock_guard<std::mutex> lk(mu);
+    if (by_dev[dev]) return by_dev[dev];
+    uint32_t answer = 0;
+    uint32_t* d = nullptr;
+    if (hipMalloc(&d, 2u * sizeof(uint32_t)) == hipSuccess) {
+        const uint32_t init[2] = {0u, 0xFFFFFFFFu};
+        lzf::fed_args a{}; a.census = d;
+        if (hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, st) == hipSuccess) {
+            hipLaunchKernelGGL(k_fed32, dim3(40u * cu_count()), dim3(64), 0, st, a);
+            uint32_t got[2] = {0, 0};
+            if (hipGetLastError() == hipSuccess && hipMemcpyAsync(got, d, sizeof got, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
+                got[1] != 0xFFFFFFFFu && got[1] >= cu_count()) answer = got[1];
+        }
+        (void)hipFree(d);
+    }
+    (void)hipGetLastError();
+    if (!answer) answer = per_cu(7680u) * cu_count();                // (the census failed: the LDS granule's answer for 6 912 bytes)
+#ifdef LZF_ANALYSIS
+    if (getenv("LZF_FED_VERBOSE")) fprintf(stderr, "[lzf] bitmap-fed kernel: %u workgroups resident at once (%u compute units)\n", answer, cu_count());
+#endif
+    by_dev[dev] = answer;
+    return answer;
+}
+int fed_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n, const uint32_t* perm, hipStream_t st, bool* used, uint64_t max_in_hint) {
+    *used = false;
+    if (n > kFedMaxJobs || max_in_hint < fed_min_in()) return LZF_OK;
+    SegScratch s;
+    lzf::seg_ctx& c = s.ctx;
+    c = lzf::seg_ctx{};
+    c.jobs = d_jobs; c.results = d_results; c.n_jobs = n;
+    const uint32_t max_in = max_in_hint < kSegMaxIn ? (uint32_t)(max_in_hint < lzf::kSegChunk ? lzf::kSegChunk : max_in_hint) : kSegMaxIn;
+    c.max_in = max_in; c.min_in = fed_min_in();
+    c.maxch = seg_nch_host(max_in);
+    c.maxtile = (max_in + lzf::kSegTile - 1u) / lzf::kSegTile;
+    c.n_cu = cu_count();
+    c.g_off = 0u; c.g_n = n; c.fed = 1u;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_st = take(sizeof(lzf::seg_job) * (size_t)n);
+    const size_t o_top = take(sizeof(unsigned long long));
+    const size_t o_x = take(sizeof(uint32_t) * (size_t)n * c.maxch);
+    const size_t o_vf = take(sizeof(uint32_t) * (size_t)n * c.maxch);
+    const size_t o_bits = take(sizeof(uint32_t) * (size_t)n * c.maxch * lzf::kSegChunkWords);
+    const size_t o_tick = take(sizeof(uint32_t));
+    const size_t o_fst = take(sizeof(lzf::fed_state) * (size_t)n);
+    if (off > kFedMaxScratch) return LZF_OK;                         // (the pair kernel takes the call)
+    if (hipMallocAsync(&s.base, off, st) != hipSuccess) { (void)hipGetLastError(); return LZF_OK; }
+    uint8_t* b = static_cast<uint8_t*>(s.base);
+    c.st = reinterpret_cast<lzf::seg_job*>(b + o_st);
+    c.rec_top = reinterpret_cast<unsigned long long*>(b + o_top);
+    c.xexit = reinterpret_cast<uint32_t*>(b + o_x);
+    c.vfrom = reinterpret_cast<uint32_t*>(b + o_vf);
+    c.bits = reinterpret_cast<uint32_t*>(b + o_bits);
+    *used = true;
+    // The kernel runs as one wavefront per SLOT — as many as the device holds at once — and the slots share the jobs out in pieces
+    // (lz4_decompress_fed.hip): a call with more jobs than slots cuts every job into 8 (measured at 2.2 jobs per slot: 107 ms whole,
+    // 98.2 / 99.8 / 104 / 115 ms with 8 / 16 / 32 / 64 pieces — a hand-over is a write-back of the XCD's L2), a smaller one leaves them whole.
+    uint32_t slots = fed_slots(st);
+    uint32_t pieces = n > slots ? 8u : 1u;
+    uint32_t pad = 0;
+#ifdef LZF_ANALYSIS      // LZF_FED_PIECES = pieces per job (A/B), LZF_FED_SLOTS = slots per CU, LZF_FED_PAD_LDS = bytes of unused LDS per wavefront (residency experiment)
+    { static const long e = [] { const char* v = getenv("LZF_FED_PIECES"); return v ? atol(v) : 0L; }(); if (e >= 1 && e <= 4096) pieces = (uint32_t)e; }
+    { static const long e = [] { const char* v = getenv("LZF_FED_SLOTS"); return v ? atol(v) : 0L; }(); if (e > 0) slots = (uint32_t)e * cu_count(); }
+    { static const uint32_t e = [] { const char* v = getenv("LZF_FED_PAD_LDS"); return v ? (uint32_t)atol(v) : 0u; }(); pad = e; }
+#endif
+    if ((uint64_t)n * pieces > 0xFFFFFFF0ull) pieces = 1u;
+    int rc = seg_launch(c, 3u, st);                                  // plan, parse, seam
+    if (rc == LZF_OK) {
+        lzf::fed_args a{d_jobs, d_results, c.st, c.bits, c.vfrom, perm, reinterpret_cast<lzf::fed_state*>(b + o_fst), reinterpret_cast<uint32_t*>(b + o_tick), n, c.maxch, pieces, nullptr};
+        hipLaunchKernelGGL(lzf::lzf_fed_reset_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(k_fed32, dim3(slots < n ? slots : n), dim3(64), pad, st, a);
+        if (hipGetLastError() != hipSuccess) rc = LZF_E_HIP;
+    }
+    if (rc == LZF_OK) {
+        hipLaunchKernelGGL(k_paired24, dim3(n), dim3(128), 0, st, d_jobs, d_results, n, perm, (const lzf::seg_job*)c.st);
+        if (hipGetLastError() != hipSuccess) rc = LZF_E_HIP;
+    }
+    if (hipFreeAsync(s.base, st) != hipSuccess && rc == LZF_OK) rc = LZF_E_HIP;
+    if (rc != LZF_OK) g_last_error = "bitmap-fed decompress: launch failed";
+    return rc;
+}
+
 #ifdef LZF_ANALYSIS
 #include "analysis/capi_analysis.inc"
 #endif
@@ -510,7 +618,7 @@ int lzf_decompress_batch_sized(const lzf_decompress_job* d_jobs, lzf_job_result*
     // wavefronts), then the pair kernel over the jobs it left (prefix / existing output, errors, sizes outside its window).
     uint32_t seg_min_in = kSegMinIn; bool seg_on = n_jobs <= seg_max_jobs();
 #ifdef LZF_ANALYSIS
-    { static const int mode = [] { const char* e = getenv("LZF_DECOMPRESS_KERNEL"); return !e ? 0 : !strcmp(e, "seg") ? 1 : !strcmp(e, "noseg") ? 2 : 0; }();
+    { static const int mode = [] { const char* e = getenv("LZF_DECOMPRESS_KERNEL"); return !e ? 0 : !strcmp(e, "seg") ? 1 : (!strcmp(e, "noseg") || !strcmp(e, "fed")) ? 2 : 0; }();
       static const uint32_t min_in = [] { const char* e = getenv("LZF_SEG_MIN_IN"); return e ? (uint32_t)atol(e) : 0u; }();
       if (mode == 1) { seg_on = true; seg_min_in = min_in; }
       if (mode == 2) seg_on = false; }
@@ -528,6 +636,18 @@ int lzf_decompress_batch_sized(const lzf_decompress_job* d_jobs, lzf_job_result*
     // (smaller LDS footprint, more blocks in flight); batches of more than eight times that many blocks (small blocks,
     // typically) go to the one-wave staged16 kernel, which has no per-block pipeline to fill.
     const uint32_t resident48 = per_cu(20u * 1024u) * cu_count();      // workgroups of the 48-byte form one device holds (20 KB of LDS each: 8 per CU on MI355X)
+    bool fed_on = n_jobs > resident48;
+#ifdef LZF_ANALYSIS
+    { static const int mode = [] { const char* e = getenv("LZF_DECOMPRESS_KERNEL"); return !e ? 0 : !strcmp(e, "fed") ? 1 : !strcmp(e, "nofed") ? 2 : 0; }();
+      if (mode == 1) fed_on = true;
+      if (mode == 2) fed_on = false; }
+#endif
+    if (fed_on) {
+        bool used = false;
+        rc = fed_decompress(d_jobs, d_results, n_jobs, cperm, st, &used, max_input_len);
+        if (used) g_last_decompress = "bitmap-fed: lzf_seg_parse_kernel + lzf_decompress_fed_kernel<4096,32,352> + lzf_decompress_paired_kernel<4096,24,384>";
+        if (rc != LZF_OK || used) { HIP_TRY(perm_owner.release()); return rc; }
+    }
     g_last_decompress = n_jobs <= resident48 ? "lzf_decompress_paired_kernel<4096,48,640>" : n_jobs <= 8u * resident48 ? "lzf_decompress_paired_kernel<4096,24,384>"
                                                                                                              : "lzf_decompress_batched_kernel<4096,16,256,staged>";
     if (n_jobs <= resident48)

@@ -103,7 +103,38 @@ struct seg_ctx {
     // One group: g_off = 0, g_n = n_jobs, grouped = 0.
     uint32_t g_off, g_n, grouped;
     uint32_t res_prio;           // the resolve stage's wavefronts raise their issue priority (grouped calls: they share their SIMDs with the next group's records stage)
+    uint32_t fed;                // the plan / parse / seam stages serve the bitmap-fed kernel: prefix and existing output do not make a job ineligible
 };
+// ---------------------------------------------------------------------------------------------------------------------
+// Bitmap-fed decompress (lz4_decompress_fed.hip): batches beyond what the chip holds at once.  plan + parse + seam of the
+// segmented pipeline run over the whole batch (seg_ctx::fed: a job's prefix / existing output do not matter to the parse),
+// then one wavefront per block lists its tokens from the bit map — verifying the chain link by link — and copies.  A job the
+// kernel does not finish cleanly stays !done for the pair kernel launched behind it.
+// ---------------------------------------------------------------------------------------------------------------------
+// decoder state a job's pieces hand on: flag = pieces finished so far (piece p starts when it reads p), kFedEnded once the job needs no more
+struct fed_state { uint32_t flag, cstart, expect, o; };
+constexpr uint32_t kFedEnded = 0x80000000u;
+struct fed_args {
+    const lzf_decompress_job* jobs;
+    lzf_job_result* results;
+    seg_job* st;
+    const uint32_t* bits;        // seg_ctx::bits
+    const uint32_t* vfrom;       // seg_ctx::vfrom
+    const uint32_t* perm;        // launch order: rank -> job (optional)
+    fed_state* state;            // [n_jobs]
+    uint32_t* ticket;            // the launch's ticket counter
+    uint32_t n_jobs, maxch;
+    uint32_t pieces;             // every job goes through the kernel in this many pieces (1: whole)
+    uint32_t* census;            // not null: the launch only counts how many of its workgroups the device holds at once ([0] arrivals, [1] the answer)
+};
+__global__ void lzf_fed_reset_kernel(fed_args a);
+// X(name, ring bytes, bit-map words per round, token-list entries)
+#define LZF_FED_VARIANTS(X) X(fed32, 4096, 32, 352)
+template <int RING, int W, int TOKCAP>
+__global__ __launch_bounds__(64) void lzf_decompress_fed_kernel(fed_args a);
+#define LZF_EXTF(NAME, RG, W_, T) extern template __global__ void lzf_decompress_fed_kernel<RG, W_, T>(fed_args);
+LZF_FED_VARIANTS(LZF_EXTF)
+#undef LZF_EXTF
 // grid row / workgroup index of a group's launch -> job
 __device__ __forceinline__ uint32_t seg_job_of(const seg_ctx& c, uint32_t i) { return c.by_len ? c.by_len[i + c.g_off] : i + c.g_off; }
 constexpr uint32_t kSegRegion = 256, kSegChunk = 64u * kSegRegion, kSegOverlap = 2048, kSegStride = kSegChunk - kSegOverlap;

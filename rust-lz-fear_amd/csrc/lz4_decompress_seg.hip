@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void lzf_seg_plan_kernel(seg_ctx c) {
     const lzf_decompress_job job = c.jobs[j];
     seg_job s;
     s.failed = 0; s.done = 0; s.ntok = 0; s.outb = 0; s.pad = 0; s.rec_off = 0; s.pad2 = 0;
-    s.eligible = (job.prefix_len == 0 && job.out_existing_len == 0 && job.input_len >= c.min_in && job.input_len <= c.max_in &&
+    s.eligible = ((c.fed || (job.prefix_len == 0 && job.out_existing_len == 0)) && job.input_len >= c.min_in && job.input_len <= c.max_in &&
                   job.input != nullptr && job.out != nullptr) ? 1u : 0u;
     const uint32_t len = s.eligible ? (uint32_t)job.input_len : 0u;
     s.nch = s.eligible ? seg_nch(len) : 0u;

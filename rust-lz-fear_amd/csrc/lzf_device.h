@@ -1,6 +1,6 @@
 // lzf_device.h — shared device-side helpers for the gfx950 LZ4 kernels (wave64 only).
 #pragma once
-#if !defined(LZF_ANALYSIS) && (defined(LZF_DBG_SKIP) || defined(LZF_DBG_SKIP2) || defined(LZF_DBG_TIME) || defined(LZF_DBG_COUNT) || defined(LZF_DBG_DRY_MAIN) || defined(LZF_DBG_LDS_PAD) || defined(LZF_DBG_PATHS) || defined(LZF_DBG_PHASE_SEL) || defined(LZF_DBG_ROUNDS) || \
+#if !defined(LZF_ANALYSIS) && (defined(LZF_DBG_SKIP) || defined(LZF_DBG_SKIP2) || defined(LZF_DBG_TIME) || defined(LZF_DBG_COUNT) || defined(LZF_DBG_DRY_MAIN) || defined(LZF_DBG_LDS_PAD) || defined(LZF_DBG_PATHS) || defined(LZF_DBG_PHASE_SEL) || defined(LZF_DBG_ROUNDS) || defined(LZF_DBG_TIMELINE) || \
     defined(LZF_SEG_DBG_SKIP) || defined(LZF_SEG_DBG_NOWAIT) || defined(LZF_SEG_TIME) || defined(LZF_SEG_NOASM) || defined(LZF_SEG_NORLE))
 #error "LZF_DBG_* / LZF_SEG_* instrumentation is for -DLZF_ANALYSIS builds only"
 #endif
@@ -115,6 +115,9 @@ __device__ __forceinline__ void lds_ld32x2(uint32_t a0, uint32_t a1, uint32_t& v
 }
 __device__ __forceinline__ void lds_ld16x2(uint32_t a0, uint32_t a1, uint32_t& v0, uint32_t& v1) {
     asm volatile("ds_read_u16 %0, %2\n\tds_read_u16 %1, %3\n\ts_waitcnt lgkmcnt(0)" : "=&v"(v0), "=&v"(v1) : "v"(a0), "v"(a1) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_ld16(uint32_t a) {
+    uint32_t v; asm volatile("ds_read_u16 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory"); return v;
 }
 __device__ __forceinline__ uint32_t lds_ld8(uint32_t a) {
     uint32_t v; asm volatile("ds_read_u8 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory"); return v;

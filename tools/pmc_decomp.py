@@ -35,6 +35,52 @@ for it in range(reps):
 if os.environ.get("LZF_PRINT_RESERVED"):
     r2 = device.results_to_host(d_res2, m)
     print(f"reserved: mean {r2['reserved'].mean():.1f} kcycles/job, sum {int(r2['reserved'].sum())} ; status ok {int((r2['status'] == 0).sum())}/{m}", flush=True)
+if os.environ.get("LZF_PER_BLOCK"):
+    # per distinct block: compressed bytes, tokens (host walk), mean kilo-cycles of its copies (run with LZF_FED_SLOTS=0: one job per workgroup)
+    r2 = device.results_to_host(d_res2, m)
+    comp_h = d_out.cpu().numpy()
+    print("block  C  tokens  litbytes  kcycles")
+    for b in order:
+        c = comp_h[int(b) * BS:int(b) * BS + int(res['out_len'][b])].tobytes(); p = 0; ntok = 0; lit = 0; L_ = len(c)
+        while p < L_:
+            t = c[p]; p += 1; l = t >> 4
+            if l == 15:
+                while True:
+                    x = c[p]; p += 1; l += x
+                    if x != 255: break
+            p += l; lit += l; ntok += 1
+            if L_ - p < 2: break
+            p += 2
+            if (t & 15) == 15:
+                while True:
+                    x = c[p]; p += 1
+                    if x != 255: break
+        kc = r2['reserved'][idx == b].mean()
+        print(int(b), L_, ntok, lit, f"{kc:.0f}", flush=True)
+if os.environ.get("LZF_TIMELINE"):
+    # -DLZF_DBG_TIMELINE build: reserved = start << 16 | end on the 100 MHz wall clock, units of 2.56 us -> jobs running over time
+    r2 = device.results_to_host(d_res2, m)
+    st = (r2['reserved'] >> 16).astype(np.int64); en = (r2['reserved'] & 0xFFFF).astype(np.int64)
+    u = np.unique(st); gaps = np.diff(np.concatenate([u, [u[0] + 65536]]))      # 16-bit circular time: the launch starts behind the largest gap
+    t0 = int(u[(int(gaps.argmax()) + 1) % len(u)])
+    st = (st - t0) % 65536; en = (en - t0) % 65536
+    us = 2.56
+    print(f"timeline: first start {st.min() * us:.0f} us, last start {st.max() * us / 1e3:.2f} ms, last end {en.max() * us / 1e3:.2f} ms, mean duration {(en - st).mean() * us / 1e3:.2f} ms")
+    print(f"  durations (ms): min {(en - st).min() * us / 1e3:.2f}, median {float(np.median(en - st)) * us / 1e3:.2f}, max {(en - st).max() * us / 1e3:.2f}")
+    edges = np.arange(0, en.max() + 1, max(1, int(5000 / us)))
+    for e in edges:
+        running = int(((st <= e) & (en > e)).sum())
+        print(f"  t = {e * us / 1e3:6.1f} ms: {running:5d} jobs running, {int((st <= e).sum()):5d} started, {int((en <= e).sum()):5d} done")
+if os.environ.get("LZF_SIM_SLOTS"):
+    # greedy list schedule of the jobs' own wave times (longest first) on S slots: how much of the launch is packing loss?
+    import heapq
+    r2 = device.results_to_host(d_res2, m)
+    t = np.sort(r2['reserved'].astype(np.float64))[::-1] * 1024.0
+    for S in [int(x) for x in os.environ["LZF_SIM_SLOTS"].split(",")]:
+        h = [0.0] * S
+        for x in t:
+            heapq.heappush(h, heapq.heappop(h) + x)
+        print(f"slots {S}: ideal {t.sum() / S / 1e6:.1f} Mcycles, greedy makespan {max(h) / 1e6:.1f} Mcycles, longest job {t[0] / 1e6:.1f}, shortest {t[-1] / 1e6:.1f}, median {t[len(t) // 2] / 1e6:.1f}", flush=True)
 if os.environ.get("LZF_VERIFY"):
     r2 = device.results_to_host(d_res2, m)
     bad = 0
