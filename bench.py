@@ -151,20 +151,29 @@ def cpu_baseline(raw_blocks, comp_blocks, budget_s):
 
 # --------------------------------------------------------------------------------------- HBM traffic (PMC passes under profiles/)
 def traffic_for(kernel_name, which, n_jobs):
-    """HBM bytes per launch of the named kernel: FETCH_SIZE (x2: gfx950 correction) + WRITE_SIZE from the separate --pmc passes
-    committed under profiles/ (tools/refresh_profiles.sh), SCALED by job count from the pass's own (smaller) batch — the second
-    value says from how many copies; (None, None) when the committed profile is of another kernel."""
+    """HBM bytes per call of the named path: FETCH_SIZE (x2: gfx950 correction) + WRITE_SIZE from the separate --pmc passes committed
+    under profiles/ (tools/refresh_profiles.sh), summed over every kernel the call launches.  `which` = "decompress" (the headline
+    call: the pass runs at 48 copies — counter collection at 240 does not finish — and is SCALED by job count), "tile20" (the pass
+    runs at exactly this size: measured, not scaled) or "compress".  The second value says which; (None, None) when the committed
+    profile is of other kernels than the ones this run launched."""
     tj = path = None
-    for name in ("r05_hbm_traffic.json", "r04_hbm_traffic.json", "r03_hbm_traffic.json", "r02_hbm_traffic.json"):
+    for name in ("r06_hbm_traffic.json", "r05_hbm_traffic.json"):
         path = os.path.join(ROOT, "profiles", name)
         if os.path.exists(path):
             tj = json.load(open(path)).get(which)
-            break
-    if not tj or tj.get("kernel", "").split("<")[0] != kernel_name.split("<")[0].split(" +")[0]:
+            if tj:
+                break
+    if not tj:
         return None, None
-    return ((2 * tj["FETCH_SIZE_KB"] + tj["WRITE_SIZE_KB"]) * 1024.0 * n_jobs / tj["jobs"],
-            {"kind": "scaled from a separate PMC pass", "scaled_from_copies": int(round(tj["jobs"] / (49.0 if which == "decompress" else 51.0))),
-             "scaled_from_jobs": int(tj["jobs"]), "profile": os.path.basename(path)})
+    head = lambda k: k.split("<")[0].split(" +")[0].split(":")[0].strip()        # noqa: E731
+    if head(tj.get("kernel", "")) != head(kernel_name):
+        return None, None
+    scale = float(n_jobs) / float(tj["jobs"])
+    measured = abs(scale - 1.0) < 0.02
+    info = {"kind": "measured at this size by a separate PMC pass" if measured else "scaled by job count from a separate PMC pass at a smaller size",
+            "pass_jobs": int(tj["jobs"]), "this_run_jobs": int(n_jobs), "profile": os.path.basename(path),
+            "formula": "2 x FETCH_SIZE + WRITE_SIZE over every kernel of the call (gfx950: FETCH_SIZE counts half of wide streaming reads)"}
+    return (2 * tj["FETCH_SIZE_KB"] + tj["WRITE_SIZE_KB"]) * 1024.0 * scale, info
 
 
 def last_decompress_launch(ffi):
@@ -173,15 +182,19 @@ def last_decompress_launch(ffi):
 
 
 def issue_ceiling(copies, kernel_ms, achieved_gbs, cus=256, which="decompress"):
-    ipseq, seq_per_copy, best_rate = 27.96, 11.71e6, 3.29            # wave-instructions per sequence; sequences per copy; instr / ns / CU (32 waves per CU)
-    kind = "model (constants from the r01 / r02 counter passes, not re-measured in this run; only kernel_ms is this run's)"
-    pc = os.path.join(ROOT, "profiles", "r05_issue_counters.json")
-    if os.path.exists(pc):                                            # round 5: the instruction counters re-measured with the round's kernels (tools/refresh_profiles.sh)
-        m = json.load(open(pc)).get(which)
-        if m:
-            ipseq = float(m["wave_instructions_per_sequence"])
-            kind = "wave-instructions per sequence from this round's PMC pass (profiles/r05_issue_counters.json: %s), kernel_ms from this run, best_rate from tools/issue_mix_microbench.hip (r01)" % (
-                ", ".join(f"{k[9:]} {v}" for k, v in sorted(m["per_sequence"].items()) if k.startswith("SQ_INSTS")))
+    """What the call retires against what a dependent SALU + VALU mix reaches on this chip (tools/issue_mix_microbench.hip, r01: 3.29
+    wave-instructions / ns / CU at 32 waves per CU).  Wave-instructions per sequence from the round's PMC pass (all kernels of the call)."""
+    ipseq, seq_per_copy, best_rate = 27.96, 11.71e6, 3.29
+    kind = "model (constants from earlier counter passes; only kernel_ms is this run's)"
+    for name in ("r06_issue_counters.json", "r05_issue_counters.json"):
+        pc = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(pc):
+            m = json.load(open(pc)).get(which)
+            if m:
+                ipseq = float(m["wave_instructions_per_sequence"])
+                kind = "wave-instructions per sequence from the PMC pass profiles/%s (%s), kernel_ms from this run, best_rate from tools/issue_mix_microbench.hip (r01)" % (
+                    name, ", ".join(f"{k[9:]} {v}" for k, v in sorted(m["per_sequence"].items()) if k.startswith("SQ_INSTS")))
+                break
     rate = ipseq * seq_per_copy * copies / (kernel_ms * 1e-3) / 1e9 / cus
     ceil_gbs = achieved_gbs * best_rate / rate
     return {"kind": kind, "wave_instructions_per_sequence": ipseq, "retired_per_ns_per_cu": round(rate, 3), "best_measured_mix_per_ns_per_cu": best_rate,
@@ -243,6 +256,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-config4", action="store_true", help="silesia workload: skip the strong-scaled configs[3] leg of the line")
     ap.add_argument("--no-config5", action="store_true", help="silesia workload: skip the configs[4] leg of the line (linked 64 KiB blocks + dictionary, U16Table)")
+    ap.add_argument("--no-sweep", action="store_true", help="silesia workload: skip the batch-size sweep and the tile20 leg (PMC passes: the headline call's kernels only)")
     ap.add_argument("--streams", type=int, default=4096, help="config5: linked-block streams of 1 MiB per GPU")
     ap.add_argument("--launch-check", action="store_true",
                     help="no GPU work: every rank joins a gloo group, the ranks agree on their block ranges, rank 0 prints them (test of the self-launch path)")
@@ -292,29 +306,68 @@ def main():
         line = run_config5(args, torch, device, ffi, dist, rank, world, dev)
     else:
         line = run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases)
+        # The two legs below run BEHIND the Silesia measurement and must never take its line down with them (a first multi-GPU run
+        # executes code no one-GPU box ever has): a failure becomes {"error": ...} under the leg's key, on every rank alike.
+        def leg(name, fn, timeout_s=900.0):
+            import threading
+            import traceback
+
+            def bail():                     # a leg that hangs (a collective one rank never enters) cannot be interrupted from Python:
+                if rank == 0 and line is not None:      # the watchdog emits the Silesia line without it and ends the process
+                    line[name] = {"error": f"the {name} leg did not return within {timeout_s:.0f} s; the line was emitted without it"}
+                    emit(line)
+                os._exit(0)
+            wd = threading.Timer(timeout_s, bail); wd.daemon = True; wd.start()
+            ok, out = 1, None
+            try:
+                out = fn()
+            except BaseException as e:      # noqa: BLE001
+                ok, out = 0, {"error": f"{type(e).__name__}: {e}", "where": traceback.format_exc()[-1500:]}
+                log(f"[bench] rank {rank}: the {name} leg failed: {out['error']}")
+            if dist:                        # every rank must leave the leg (its collectives) before the next one starts
+                try:
+                    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    if int(flag[0]) == 0 and ok:
+                        out = {"error": "another rank failed in this leg"}
+                except BaseException as e:  # noqa: BLE001
+                    out = {"error": f"{name}: the ranks could not agree on the outcome: {e}"}
+            wd.cancel()
+            return out
         if not args.no_config4:
             # the one workload with a real exchange (BASELINE configs[3]), strong-scaled, as a leg of the same line: a driver
             # run at N GPUs records the weak-scaled Silesia value and this
             import copy, gc
-            gc.collect(); torch.cuda.empty_cache()
-            a4 = copy.copy(args); a4.steps = max(1, min(args.steps, 3)); a4.warmup = 1; a4.no_cpu = True
-            l4 = run_config4(a4, torch, device, ffi, dist, rank, world, dev)
+
+            def c4():
+                gc.collect(); torch.cuda.empty_cache()
+                a4 = copy.copy(args); a4.steps = max(1, min(args.steps, 3)); a4.warmup = 1; a4.no_cpu = True
+                l4 = run_config4(a4, torch, device, ffi, dist, rank, world, dev)
+                if rank != 0:
+                    return None
+                return {"value": l4["value"], "unit": l4["unit"], "scaling": "strong", "steps": a4.steps, "ms_per_step": l4["ms_per_step"],
+                        "compress_ms": l4["roofline"]["kernel_ms"], "gather_ms": l4["config"]["gather_ms"],
+                        "wire_bytes_in_per_rank": l4["config"]["wire_bytes_in_per_rank"], "frame_bytes": l4["config"]["frame_bytes"],
+                        "n_ranks_seen_by_rccl": l4["config"]["n_ranks_seen_by_rccl"], "gather_path": l4["config"]["gather_path"], "blocks": l4["config"]["blocks"],
+                        "librccl": l4["config"]["librccl"],
+                        "compress_launch": l4["roofline"]["kernel"],
+                        "verified_against_oracle_prefix": l4["config"]["verified_against_oracle_prefix"],
+                        "content_checksum": l4["config"]["content_checksum"]}
+            r4 = leg("config4", c4)
             if rank == 0:
-                line["config4"] = {"value": l4["value"], "unit": l4["unit"], "scaling": "strong", "steps": a4.steps, "ms_per_step": l4["ms_per_step"],
-                                   "compress_ms": l4["roofline"]["kernel_ms"], "gather_ms": l4["config"]["gather_ms"],
-                                   "wire_bytes_in_per_rank": l4["config"]["wire_bytes_in_per_rank"], "frame_bytes": l4["config"]["frame_bytes"],
-                                   "n_ranks_seen_by_rccl": l4["config"]["n_ranks_seen_by_rccl"], "gather_path": l4["config"]["gather_path"], "blocks": l4["config"]["blocks"],
-                                   "compress_launch": l4["roofline"]["kernel"],
-                                   "verified_against_oracle_prefix": l4["config"]["verified_against_oracle_prefix"],
-                                   "content_checksum": l4["config"]["content_checksum"]}
+                line["config4"] = r4
         if not args.no_config5 and world == 1:
             # configs[4]: linked 64 KiB blocks behind a dictionary (many streams in lock-step) and raw U16Table jobs, device-resident
             import copy, gc
-            gc.collect(); torch.cuda.empty_cache()
-            a5 = copy.copy(args); a5.steps = max(1, min(args.steps, 3)); a5.warmup = 1
-            l5 = run_config5(a5, torch, device, ffi, dist, rank, world, dev)
+
+            def c5():
+                gc.collect(); torch.cuda.empty_cache()
+                a5 = copy.copy(args); a5.steps = max(1, min(args.steps, 3)); a5.warmup = 1
+                l5 = run_config5(a5, torch, device, ffi, dist, rank, world, dev)
+                return {k: l5[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "roofline", "compress", "u16_raw")} if rank == 0 else None
+            r5 = leg("config5", c5)
             if rank == 0:
-                line["config5"] = {k: l5[k] for k in ("value", "unit", "steps", "ms_per_step", "config", "roofline", "compress", "u16_raw")}
+                line["config5"] = r5
     if rank == 0:
         emit(line)
     if dist:
@@ -469,8 +522,8 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
     c_achieved = c_bytes / (c_kernel_ms * 1e-3) / 1e9
 
     # ------------------------------------------------------------------ batch-size sweep of the same call (this rank's first copies)
-    sweep = None
-    if rank == 0:
+    sweep = tile20 = None
+    if rank == 0 and not args.no_sweep:
         sweep = {}
         per_copy = max(1, nk // copies)
         for c_n in (1, 4, 20):
@@ -487,6 +540,18 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
             assert np.all(r_["status"] == ffi.OK) and np.array_equal(r_["out_len"], lens[kidx[:m]])
             ms = float(sorted(ts[1:])[2])
             sweep[str(m)] = {"ms": round(ms, 3), "gibs": round(float(lens[kidx[:m]].sum()) / (ms * 1e-3) / 2**30, 2), "launch": last_decompress_launch(ffi)}
+            if c_n == 20:
+                # BASELINE.md's planned throughput tile ("tiled x20 with distinct seeds, 1020 blocks") as a leg of its own:
+                # the same call over the first 20 copies' compressed blocks, with its own roofline (HBM traffic MEASURED at this size)
+                t_bytes = float(lens[kidx[:m]].sum() + clen[kidx[:m]].sum())
+                t_ach = t_bytes / (ms * 1e-3) / 1e9
+                t_traffic, t_info = traffic_for(sweep[str(m)]["launch"], "tile20", m)
+                tile20 = {"value": sweep[str(m)]["gibs"], "unit": "GiB/s (uncompressed bytes decompressed per second, one call over 20 copies)", "blocks": int(m),
+                          "copies": 20, "ms_per_step": round(ms, 3),
+                          "roofline": {"bound": "hbm", "kernel": sweep[str(m)]["launch"], "achieved": round(t_ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(t_ach / HBM_PEAK_GBS, 5), "traffic": t_traffic, "traffic_provenance": t_info,
+                                       "algorithmic_bytes_per_launch": t_bytes, "kernel_ms": round(ms, 3),
+                                       "north_star_frac": round(float(lens[kidx[:m]].sum()) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}}
         sweep[str(nk)] = {"ms": round(d_kernel_ms, 3), "gibs": round(float(lens[kidx].sum()) / (d_kernel_ms * 1e-3) / 2**30, 2), "launch": kname_main}
         if not args.no_verify:
             assert torch.equal(dec, src), "decoded bytes differ from the source after the batch sweep"
@@ -544,6 +609,8 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
         # the same call at smaller batch sizes (compressed blocks of the first 1 / 4 / 20 copies; kernel time by HIP events,
         # median of 5): up to 1024 blocks go through the segmented pipeline, a block decoded by many wavefronts
         "batch_sweep": sweep,
+        # the x20 tile of BASELINE.md / SURVEY §8(d) (1 020 blocks, 980 of them compressed): its own value and roofline
+        "tile20": tile20,
         "cpu_baseline": cpu,
         "end_to_end": e2e,
     }
@@ -654,6 +721,31 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
             comm.close(); comm = None
             gather_path = "torch.distributed (all_gather_into_tensor + batch_isend_irecv) [fallback: another rank could not make the communicator]"
 
+    # which librccl the exchange library is bound to, next to every copy mapped into this process (torch carries its own)
+    try:
+        librccl = lzdist.rccl_paths()
+    except Exception as e:      # noqa: BLE001
+        librccl = {"error": str(e)}
+    # a first exchange outside the timed region: if the C path fails at STEP time on any rank (lzf_frame_gather returns the same code on
+    # every rank for what one rank can see, include/lzfear_dist.h), every rank moves to the torch path together
+    if comm:
+        ok = 1
+        try:
+            device.compress_batch(d_cj, d_cres, nloc, ffi.KINDS_U32 | ffi.KINDS_U32_FRESH_ONLY)
+            lzdist.gather_frame_device_c(comm, d_cres, comp, src, BS, nloc, nblk_all, frame, header)
+        except Exception as e:      # noqa: BLE001
+            ok = 0
+            log(f"[bench] rank {rank}: lzf_frame_gather failed at step time ({e}); falling back to torch.distributed")
+            gather_path = f"torch.distributed (all_gather_into_tensor + batch_isend_irecv) [fallback: lzf_frame_gather failed: {e}]"
+        if dist and world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag[0]) == 0 and ok:
+                ok = 0
+                gather_path = "torch.distributed (all_gather_into_tensor + batch_isend_irecv) [fallback: lzf_frame_gather failed on another rank]"
+        if not ok:
+            comm.close(); comm = None
+
     kev, gev = [], []
 
     def step():
@@ -745,7 +837,7 @@ def run_config4(args, torch, device, ffi, dist, rank, world, dev):
                    "blocks": nblk_all, "block_size": BS, "parallelism": f"block ranges x{world}, all-gather over RCCL",
                    "frame_bytes": int(state["frame_len"]), "wire_bytes_in_per_rank": int(wire), "verified_against_oracle_prefix": verified,
                    "gather_ms": round(g_ms, 3), "gather_path": gather_path,
-                   "n_ranks_seen_by_rccl": n_seen, "content_checksum": xx},
+                   "n_ranks_seen_by_rccl": n_seen, "librccl": librccl, "content_checksum": xx},
         "roofline": {"bound": "hbm", "kernel": state["launch"], "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic_for(state["launch"], "compress", nloc)[0],
                      "algorithmic_bytes_per_launch": alg, "kernel_ms": round(k_ms, 4)},

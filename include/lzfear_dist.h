@@ -38,13 +38,19 @@ void lzf_dist_comm_free(lzf_dist_comm* comm);
  * On return (after the stream is synchronised by this call) d_frame[0 .. *frame_len) on EVERY rank is the frame:
  * header[0 .. header_len) (the caller's: lzf_frame_* builds it), the blocks in order, the EndMark (no content checksum: XXH32
  * does not compose across ranks).  *comp_total = the bytes of all payloads.
- * Returns LZF_OK, LZF_E_INVALID (arguments, frame_cap too small), LZF_E_HIP, or LZF_CONTRACT (a block status that cannot be framed). */
+ * The header must not announce block checksums or a content checksum (this frame carries neither).
+ * Returns LZF_OK, LZF_E_INVALID (arguments, frame_cap too small, such a header), LZF_E_HIP, or LZF_CONTRACT (a block status that
+ * cannot be framed) — the SAME code on every rank, whichever rank the cause was on: a rank's local findings travel with the size
+ * table, so no rank returns while its peers wait in the payload exchange. */
 int lzf_frame_gather(lzf_dist_comm* comm, const lzf_job_result* d_results, const uint8_t* d_comp, const uint8_t* d_src,
                      uint64_t stride, uint64_t block_size, uint32_t n_local, uint32_t n_blocks, uint64_t last_block_len,
                      const uint8_t* header, uint32_t header_len, uint8_t* d_frame, uint64_t frame_cap,
                      uint64_t* frame_len, uint64_t* comp_total, void* hip_stream);
 
 const char* lzf_dist_last_error(void);
+/* Path of the librccl this library's calls resolve to in the running process (dladdr): a host program that carries its own RCCL
+ * (PyTorch does) can check that both bind the same one. */
+const char* lzf_dist_rccl_path(void);
 
 #ifdef __cplusplus
 }

@@ -15,8 +15,8 @@
 namespace {
 
 thread_local std::string g_last_error;
-thread_local const char* g_last_decompress = "";
-thread_local const char* g_last_compress = "";        // ... and the last lzf_compress_batch      // what the last lzf_decompress_batch of this thread launched
+thread_local const char* g_last_decompress = "";      // what the last lzf_decompress_batch of this thread launched (lzf_last_decompress_launch)
+thread_local const char* g_last_compress = "";        // ... and the last lzf_compress_batch
 
 int fail_hip(hipError_t e, const char* what) {
     char buf[256];
@@ -50,15 +50,17 @@ int ensure_device() {
 // The geometry every dispatch threshold below is derived from: compute units and LDS bytes per CU of the current device, as the
 // runtime reports them (MI355X: 256 and 160 KiB).  The thresholds are functions of those two numbers (the segmented pipeline's
 // batch limit additionally of its rank kernels' 1024-job workgroup, kSegRankMax).
-struct Geometry { uint32_t cu, lds; };
+struct Geometry { uint32_t cu, lds, wall_khz; };      // wall_khz: rate of wall_clock64() (s_memrealtime), 100 MHz on MI355X
 const Geometry& geometry() {
     static const Geometry g = [] {
-        Geometry r{256u, 160u * 1024u};
+        Geometry r{256u, 160u * 1024u, 100000u};
         hipDeviceProp_t p; int dev = 0;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) {
             r.cu = (uint32_t)p.multiProcessorCount;
             if (p.maxSharedMemoryPerMultiProcessor >= 64u * 1024u) r.lds = (uint32_t)p.maxSharedMemoryPerMultiProcessor;
-        } else (void)hipGetLastError();      // (only an error of these two calls is cleared, never one the caller left pending)
+            int khz = 0;
+            if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz >= 1000) r.wall_khz = (uint32_t)khz; else (void)hipGetLastError();
+        } else (void)hipGetLastError();      // (only an error of these calls is cleared, never one the caller left pending)
 #ifdef LZF_ANALYSIS      // LZF_FAKE_CU=n: dispatch as if the device had n compute units (test of the derived thresholds on one device)
         if (const char* e = getenv("LZF_FAKE_CU")) { const long v = atol(e); if (v >= 1 && v <= 4096) r.cu = (uint32_t)v; }
 #endif
@@ -248,10 +250,14 @@ int seg_launch(const lzf::seg_ctx& c, uint32_t upto, hipStream_t st) {
 // records are written (an event), and the caller's stream waits for all of them before the pair kernel looks for jobs the
 // pipeline left.  The call then takes records(first group) + resolve(longest block) instead of records(all) + resolve(longest
 // block), as long as the later groups — the blocks with fewer sequences — are through their shorter resolve stages by then.
-constexpr uint32_t kSegMaxGroups = 4;      // (the caller's stream + three: HIP runs four hardware queues by default, a fifth stream would share one and wait)
+constexpr uint32_t kSegMaxGroups = 4;      // (the caller's stream + three of the library's own, made at the highest stream priority: the runtime keeps a pool of hardware queues per
+                                           //  priority, so these do not share a queue with the application's streams; a fifth group measured slower: 8.9 -> 13.2 ms at 196 blocks)
 struct SegGroups { uint32_t n = 1; uint32_t size[kSegMaxGroups] = {}; };
 SegGroups seg_groups(uint32_t n_jobs) {
     SegGroups g; g.size[0] = n_jobs;
+    // (beyond what the rank kernels' one workgroup takes — only the analysis library's forced pipeline gets here — one group, in the
+    //  caller's order: ADVICE r5, the ranks of 1 024 jobs and more were never written)
+    if (n_jobs > seg_max_jobs()) return g;
     const uint32_t ncu = cu_count();
     uint32_t pct[kSegMaxGroups] = {100}; uint32_t k = 1;
     if (n_jobs >= (ncu + 7u) / 8u) { pct[0] = pct[1] = pct[2] = pct[3] = 25; k = 4; }      // (MI355X: 32 jobs and more; measured 49 .. 980 blocks: quarters beat halves and thirds)
@@ -320,9 +326,10 @@ int seg_enqueue_groups(SegScratch& s, const SegGroups& g, SegLanes& L, hipStream
     { static const int pr = [] { const char* e = getenv("LZF_SEG_PRIO"); return e ? atoi(e) : 1; }(); c.res_prio = pr ? 1u : 0u; }
 #endif
     uint32_t off = 0, forked = 0;
-    uint32_t pause_ticks = 1000u;                                // 10 us of the 100 MHz clock (5 .. 80 us measured alike)
+    const uint32_t ticks_per_us = geometry().wall_khz / 1000u;   // (the device's wall clock: 100 per microsecond on MI355X)
+    uint32_t pause_ticks = 10u * ticks_per_us;                   // 10 us (5 .. 80 us measured alike)
 #ifdef LZF_ANALYSIS      // LZF_SEG_PAUSE_US: the pause between a group's records stage and the next (A/B; 0 = none)
-    { static const int us = [] { const char* e = getenv("LZF_SEG_PAUSE_US"); return e ? atoi(e) : -1; }(); if (us >= 0) pause_ticks = (uint32_t)us * 100u; }
+    { static const int us = [] { const char* e = getenv("LZF_SEG_PAUSE_US"); return e ? atoi(e) : -1; }(); if (us >= 0) pause_ticks = (uint32_t)us * ticks_per_us; }
 #endif
     for (uint32_t k = 0; k < g.n && rc == LZF_OK; ++k) {
         c.g_off = off; c.g_n = g.size[k]; off += g.size[k];
@@ -387,31 +394,32 @@ constexpr uint32_t kFedMaxJobs = 65535u;                             // (the chu
 // does not know the LDS allocation granule (6 912 bytes take 7 680: 21 per CU, the query says 23), and a schedule with more slots
 // than residents runs its surplus slots after the others.  Once per device and process: one launch of ~0.1 ms and a 4-byte copy
 // (the one place a batch call waits for the device).
-uint32_t fed_slots(hipStream_t st) {
+struct FedGeometry { uint32_t slots, xcc_mask; };
+FedGeometry fed_geometry(hipStream_t st) {
     constexpr int kMaxDev = 64;
     static std::mutex mu;
-    static uint32_t by_dev[kMaxDev] = {};
+    static FedGeometry by_dev[kMaxDev] = {};
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) { (void)hipGetLastError(); return 8u * cu_count(); }
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) { (void)hipGetLastError(); return FedGeometry{8u * cu_count(), 0u}; }
     std::lock_guard<std::mutex> lk(mu);
-    if (by_dev[dev]) return by_dev[dev];
-    uint32_t answer = 0;
+    if (by_dev[dev].slots) return by_dev[dev];
+    FedGeometry answer{0u, 0u};
     uint32_t* d = nullptr;
-    if (hipMalloc(&d, 2u * sizeof(uint32_t)) == hipSuccess) {
-        const uint32_t init[2] = {0u, 0xFFFFFFFFu};
+    if (hipMalloc(&d, 4u * sizeof(uint32_t)) == hipSuccess) {
+        const uint32_t init[4] = {0u, 0xFFFFFFFFu, 0u, 0u};
         lzf::fed_args a{}; a.census = d;
         if (hipMemcpyAsync(d, init, sizeof init, hipMemcpyHostToDevice, st) == hipSuccess) {
             hipLaunchKernelGGL(k_fed32, dim3(40u * cu_count()), dim3(64), 0, st, a);
-            uint32_t got[2] = {0, 0};
+            uint32_t got[4] = {0, 0, 0, 0};
             if (hipGetLastError() == hipSuccess && hipMemcpyAsync(got, d, sizeof got, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess &&
-                got[1] != 0xFFFFFFFFu && got[1] >= cu_count()) answer = got[1];
+                got[1] != 0xFFFFFFFFu && got[1] >= cu_count()) { answer.slots = got[1]; answer.xcc_mask = got[2]; }
         }
         (void)hipFree(d);
     }
     (void)hipGetLastError();
-    if (!answer) answer = per_cu(7680u) * cu_count();                // (the census failed: the LDS granule's answer for 6 912 bytes)
+    if (!answer.slots) answer.slots = per_cu(7680u) * cu_count();    // (the census failed: the LDS granule's answer for 6 912 bytes; no XCD mask: jobs stay whole)
 #ifdef LZF_ANALYSIS
-    if (getenv("LZF_FED_VERBOSE")) fprintf(stderr, "[lzf] bitmap-fed kernel: %u workgroups resident at once (%u compute units)\n", answer, cu_count());
+    if (getenv("LZF_FED_VERBOSE")) fprintf(stderr, "[lzf] bitmap-fed kernel: %u workgroups resident at once (%u compute units), XCD mask 0x%x\n", answer.slots, cu_count(), answer.xcc_mask);
 #endif
     by_dev[dev] = answer;
     return answer;
@@ -436,7 +444,7 @@ int fed_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, 
     const size_t o_x = take(sizeof(uint32_t) * (size_t)n * c.maxch);
     const size_t o_vf = take(sizeof(uint32_t) * (size_t)n * c.maxch);
     const size_t o_bits = take(sizeof(uint32_t) * (size_t)n * c.maxch * lzf::kSegChunkWords);
-    const size_t o_tick = take(sizeof(uint32_t));
+    const size_t o_tick = take(sizeof(uint32_t) * 32u * lzf::kFedTicketStride);
     const size_t o_fst = take(sizeof(lzf::fed_state) * (size_t)n);
     if (off > kFedMaxScratch) return LZF_OK;                         // (the pair kernel takes the call)
     if (hipMallocAsync(&s.base, off, st) != hipSuccess) { (void)hipGetLastError(); return LZF_OK; }
@@ -448,10 +456,11 @@ int fed_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, 
     c.bits = reinterpret_cast<uint32_t*>(b + o_bits);
     *used = true;
     // The kernel runs as one wavefront per SLOT — as many as the device holds at once — and the slots share the jobs out in pieces
-    // (lz4_decompress_fed.hip): a call with more jobs than slots cuts every job into 8 (measured at 2.2 jobs per slot: 107 ms whole,
-    // 98.2 / 99.8 / 104 / 115 ms with 8 / 16 / 32 / 64 pieces — a hand-over is a write-back of the XCD's L2), a smaller one leaves them whole.
-    uint32_t slots = fed_slots(st);
-    uint32_t pieces = n > slots ? 8u : 1u;
+    // (lz4_decompress_fed.hip): a call with more jobs than slots cuts every job into 16 (measured at 2.2 jobs per slot: 107.4 ms whole, 97.3 / 97.2 / 97.8 / 99.0 / 101.7 ms with
+    // 8 / 16 / 32 / 64 / 128 pieces), a smaller one leaves them whole.
+    const FedGeometry fg = fed_geometry(st);
+    uint32_t slots = fg.slots;
+    uint32_t pieces = n > slots && fg.xcc_mask ? 16u : 1u;
     uint32_t pad = 0;
 #ifdef LZF_ANALYSIS      // LZF_FED_PIECES = pieces per job (A/B), LZF_FED_SLOTS = slots per CU, LZF_FED_PAD_LDS = bytes of unused LDS per wavefront (residency experiment)
     { static const long e = [] { const char* v = getenv("LZF_FED_PIECES"); return v ? atol(v) : 0L; }(); if (e >= 1 && e <= 4096) pieces = (uint32_t)e; }
@@ -461,7 +470,8 @@ int fed_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, 
     if ((uint64_t)n * pieces > 0xFFFFFFF0ull) pieces = 1u;
     int rc = seg_launch(c, 3u, st);                                  // plan, parse, seam
     if (rc == LZF_OK) {
-        lzf::fed_args a{d_jobs, d_results, c.st, c.bits, c.vfrom, perm, reinterpret_cast<lzf::fed_state*>(b + o_fst), reinterpret_cast<uint32_t*>(b + o_tick), n, c.maxch, pieces, nullptr};
+        if (!fg.xcc_mask) pieces = 1u;
+        lzf::fed_args a{d_jobs, d_results, c.st, c.bits, c.vfrom, perm, reinterpret_cast<lzf::fed_state*>(b + o_fst), reinterpret_cast<uint32_t*>(b + o_tick), fg.xcc_mask ? fg.xcc_mask : 1u, n, c.maxch, pieces, nullptr};
         hipLaunchKernelGGL(lzf::lzf_fed_reset_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, a);
         hipLaunchKernelGGL(k_fed32, dim3(slots < n ? slots : n), dim3(64), pad, st, a);
         if (hipGetLastError() != hipSuccess) rc = LZF_E_HIP;

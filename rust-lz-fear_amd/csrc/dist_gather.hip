@@ -5,6 +5,7 @@
 // link carries one segment once), not a padded ring all-gather.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <dlfcn.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -104,71 +105,112 @@ void lzf_dist_comm_free(lzf_dist_comm* comm) {
     delete comm;
 }
 
+// Where librccl came from in this process (dladdr on the entry this library calls): bench.py prints it beside torch's own copy.
+const char* lzf_dist_rccl_path(void) {
+    static thread_local std::string path;
+    Dl_info info;
+    path = dladdr(reinterpret_cast<void*>(&ncclCommInitRank), &info) && info.dli_fname ? info.dli_fname : "";
+    return path.c_str();
+}
+
+// The call is COLLECTIVE: whatever goes wrong on one rank before the payload exchange — an argument only this rank can judge
+// (frame_cap, header, n_local), a failed launch, a block status that cannot be framed — travels to every rank in the size table
+// (kRowExtra words per rank behind its size words: an error code and the rank's frame_cap), so that all ranks return the same
+// failure BEFORE any of them posts a send or a receive.  (a rank that returned early left its peers in ncclRecv.)
 int lzf_frame_gather(lzf_dist_comm* comm, const lzf_job_result* d_results, const uint8_t* d_comp, const uint8_t* d_src,
                      uint64_t stride, uint64_t block_size, uint32_t n_local, uint32_t n_blocks, uint64_t last_block_len,
                      const uint8_t* header, uint32_t header_len, uint8_t* d_frame, uint64_t frame_cap,
                      uint64_t* frame_len, uint64_t* comp_total, void* hip_stream) {
-    if (!comm || !d_frame || !header || !frame_len || (n_local && (!d_results || !d_comp || !d_src)) || block_size == 0 || block_size > 0x7FFFFFFFull ||
-        stride < block_size || last_block_len == 0 || last_block_len > block_size || n_blocks == 0)
+    // what every rank passes alike (a mismatch here is a bug of the caller on all ranks at once): safe to return on
+    if (!comm || !frame_len || block_size == 0 || block_size > 0x7FFFFFFFull || last_block_len == 0 || last_block_len > block_size || n_blocks == 0)
         return fail(LZF_E_INVALID, "lzf_frame_gather", "bad argument");
     const int rank = comm->rank, world = comm->world;
     uint32_t lo, hi;
     shard_range(n_blocks, rank, world, lo, hi);
-    if (hi - lo != n_local) return fail(LZF_E_INVALID, "lzf_frame_gather", "n_local is not this rank's share of n_blocks");
+    // what only this rank can judge: carried to the others as local_err
+    constexpr uint32_t kRowExtra = 4u;       // [0] error code, [1..2] frame_cap, [3] spare
+    enum : uint32_t { kErrNone = 0u, kErrArgs = 1u, kErrShare = 2u, kErrHeader = 3u, kErrLaunch = 4u, kErrStatus = 5u };
+    uint32_t local_err = kErrNone;
+    if (!d_frame || !header || (n_local && (!d_results || !d_comp || !d_src)) || stride < block_size) local_err = kErrArgs;
+    else if (hi - lo != n_local) local_err = kErrShare;
+    // the frame this call writes has no block checksums and no content checksum (XXH32 does not compose across ranks): a header that
+    // announces either would make the frame invalid (src/framed/compress.rs:259-263,:279-281; flags header.rs:8-16)
+    else if (header_len < 7u || (header[4] & 0x14u) != 0u) local_err = kErrHeader;
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     const uint32_t max_blocks = (n_blocks + (uint32_t)world - 1u) / (uint32_t)world;
-    // scratch: [tab (max_blocks u32)][tabs (world x max_blocks u32)][bad u32][sp][dp][len]
-    const size_t o_tabs = ((size_t)max_blocks * 4u + 255u) & ~(size_t)255u, o_bad = o_tabs + (((size_t)world * max_blocks * 4u + 255u) & ~(size_t)255u);
+    const uint32_t row = max_blocks + kRowExtra;
+    const uint32_t n_mine = local_err ? 0u : n_local;
+    // scratch: [tab (row u32)][tabs (world x row u32)][bad u32][sp][dp][len]
+    const size_t o_tabs = ((size_t)row * 4u + 255u) & ~(size_t)255u, o_bad = o_tabs + (((size_t)world * row * 4u + 255u) & ~(size_t)255u);
     const size_t o_sp = o_bad + 256u, o_dp = o_sp + (((size_t)n_local * 8u + 255u) & ~(size_t)255u), o_len = o_dp + (o_dp - o_sp);
     uint8_t* scratch = nullptr;
-    HIPOK(hipMallocAsync(reinterpret_cast<void**>(&scratch), o_len + (o_dp - o_sp) + 256u, st));
+    HIPOK(hipMallocAsync(reinterpret_cast<void**>(&scratch), o_len + (o_dp - o_sp) + 256u, st));      // (without memory for the table this rank cannot tell anybody: the one early return left)
     struct Free { uint8_t* p; hipStream_t s; ~Free() { if (p) (void)hipFreeAsync(p, s); } } guard{scratch, st};
     uint32_t* tab = reinterpret_cast<uint32_t*>(scratch);
     uint32_t* tabs = reinterpret_cast<uint32_t*>(scratch + o_tabs);
     uint32_t* bad = reinterpret_cast<uint32_t*>(scratch + o_bad);
-    HIPOK(hipMemsetAsync(scratch, 0, o_sp, st));
-    if (n_local) hipLaunchKernelGGL(lzf_gather_sizes_kernel, dim3(1), dim3(1024), 0, st, d_results, n_local, lo, n_blocks, block_size, last_block_len, tab, bad);
-    HIPOK(hipGetLastError());
-    // ---- the size table (one u32 per block, padded to the largest range)
-    if (world > 1) NCCLOK(ncclAllGather(tab, tabs, max_blocks, ncclUint32, comm->comm, st));
-    else HIPOK(hipMemcpyAsync(tabs, tab, (size_t)max_blocks * 4u, hipMemcpyDeviceToDevice, st));
-    std::vector<uint32_t> h_tabs((size_t)world * max_blocks + 1u);
-    HIPOK(hipMemcpyAsync(h_tabs.data(), tabs, (size_t)world * max_blocks * 4u, hipMemcpyDeviceToHost, st));
-    HIPOK(hipMemcpyAsync(&h_tabs[(size_t)world * max_blocks], bad, 4u, hipMemcpyDeviceToHost, st));
+    if (hipMemsetAsync(scratch, 0, o_sp, st) != hipSuccess) { (void)hipGetLastError(); local_err = local_err ? local_err : kErrLaunch; }
+    if (n_mine) {
+        hipLaunchKernelGGL(lzf_gather_sizes_kernel, dim3(1), dim3(1024), 0, st, d_results, n_mine, lo, n_blocks, block_size, last_block_len, tab, bad);
+        if (hipGetLastError() != hipSuccess) local_err = kErrLaunch;
+    }
+    {   // this rank's error word and frame_cap behind its size words
+        const uint32_t extra[kRowExtra] = {local_err, (uint32_t)frame_cap, (uint32_t)(frame_cap >> 32), 0u};
+        if (hipMemcpyAsync(tab + max_blocks, extra, sizeof extra, hipMemcpyHostToDevice, st) != hipSuccess) { (void)hipGetLastError(); return fail(LZF_E_HIP, "lzf_frame_gather", "cannot publish this rank's state"); }
+        if (hipStreamSynchronize(st) != hipSuccess) { (void)hipGetLastError(); return fail(LZF_E_HIP, "lzf_frame_gather", "stream"); }      // (`extra` is on this stack frame)
+    }
+    // ---- the size table (one u32 per block, padded to the largest range, + the extra words)
+    if (world > 1) NCCLOK(ncclAllGather(tab, tabs, row, ncclUint32, comm->comm, st));
+    else HIPOK(hipMemcpyAsync(tabs, tab, (size_t)row * 4u, hipMemcpyDeviceToDevice, st));
+    std::vector<uint32_t> h_tabs((size_t)world * row + 1u);
+    HIPOK(hipMemcpyAsync(h_tabs.data(), tabs, (size_t)world * row * 4u, hipMemcpyDeviceToHost, st));
+    HIPOK(hipMemcpyAsync(&h_tabs[(size_t)world * row], bad, 4u, hipMemcpyDeviceToHost, st));
     HIPOK(hipStreamSynchronize(st));                                 // (segment sizes are arguments of the sends: the host needs them)
-    uint32_t any_bad = h_tabs[(size_t)world * max_blocks];
+    // ---- every rank looks at every rank's state: from here on all ranks take the same way out
+    uint32_t worst = 0; int worst_rank = -1; uint64_t min_cap = ~0ull;
+    for (int r = 0; r < world; ++r) {
+        const uint32_t* x = &h_tabs[(size_t)r * row + max_blocks];
+        if (x[0] && !worst) { worst = x[0]; worst_rank = r; }
+        const uint64_t cap_r = (uint64_t)x[1] | ((uint64_t)x[2] << 32);
+        if (cap_r < min_cap) min_cap = cap_r;
+    }
+    if (worst) {
+        char msg[160];
+        snprintf(msg, sizeof msg, "rank %d: %s", worst_rank, worst == kErrArgs ? "bad argument" : worst == kErrShare ? "n_local is not its share of n_blocks"
+                 : worst == kErrHeader ? "the header announces block or content checksums, which this frame does not carry" : "a launch failed");
+        return fail(worst == kErrLaunch ? LZF_E_HIP : LZF_E_INVALID, "lzf_frame_gather", msg);
+    }
     std::vector<uint64_t> seg_off((size_t)world + 1u);
     seg_off[0] = header_len;
     uint64_t payload = 0;
+    // a rank with a status that cannot be framed says so through the size table: its word is zero-length (never a legal payload)
+    uint32_t any_bad = h_tabs[(size_t)world * row];
     for (int r = 0; r < world; ++r) {
         uint32_t rlo, rhi;
         shard_range(n_blocks, r, world, rlo, rhi);
-        uint64_t s = 0;
-        for (uint32_t i = 0; i < rhi - rlo; ++i) { const uint32_t n = h_tabs[(size_t)r * max_blocks + i] & 0x7FFFFFFFu; s += (uint64_t)n + 4u; payload += n; }
-        seg_off[(size_t)r + 1u] = seg_off[r] + s;
-    }
-    // a rank with a status that cannot be framed says so to everybody through the size table: its words are zero-length (never a
-    // legal payload) — every rank fails the same way instead of one rank leaving the others in a send
-    if (world > 1) {
-        for (int r = 0; r < world; ++r) {
-            uint32_t rlo, rhi; shard_range(n_blocks, r, world, rlo, rhi);
-            for (uint32_t i = 0; i < rhi - rlo; ++i) if ((h_tabs[(size_t)r * max_blocks + i] & 0x7FFFFFFFu) == 0u) any_bad = 1u;
+        uint64_t sg = 0;
+        for (uint32_t i = 0; i < rhi - rlo; ++i) {
+            const uint32_t n = h_tabs[(size_t)r * row + i] & 0x7FFFFFFFu;
+            if (n == 0u) any_bad = 1u;
+            sg += (uint64_t)n + 4u; payload += n;
         }
+        seg_off[(size_t)r + 1u] = seg_off[r] + sg;
     }
     if (any_bad) return fail(LZF_CONTRACT, "lzf_frame_gather", "a block's compress status is neither OK nor OUTPUT_FULL (or its payload is empty)");
     const uint64_t flen = seg_off[world] + 4u;
-    if (flen > frame_cap) return fail(LZF_E_INVALID, "lzf_frame_gather", "frame_cap too small");
+    if (flen > min_cap) return fail(LZF_E_INVALID, "lzf_frame_gather", "frame_cap too small (on some rank)");
     // ---- this rank's segment, packed in place
+    int pack_rc = LZF_OK;
     if (n_local) {
         const uint8_t** sp = reinterpret_cast<const uint8_t**>(scratch + o_sp);
         uint8_t** dp = reinterpret_cast<uint8_t**>(scratch + o_dp);
         uint64_t* len = reinterpret_cast<uint64_t*>(scratch + o_len);
         hipLaunchKernelGGL(lzf_gather_pack_kernel, dim3(1), dim3(1024), 0, st, tab, n_local, d_comp, d_src, stride, d_frame, seg_off[rank], sp, dp, len);
-        HIPOK(hipGetLastError());
-        const int rc = lzf_copy_ranges(sp, dp, len, n_local, block_size, st);
-        if (rc != LZF_OK) return fail(rc, "lzf_copy_ranges", lzf_last_error());
+        if (hipGetLastError() != hipSuccess) pack_rc = LZF_E_HIP;
+        else pack_rc = lzf_copy_ranges(sp, dp, len, n_local, block_size, st);
     }
-    // ---- exchange: my segment to every peer, theirs into their places (one grouped operation)
+    // ---- exchange: my segment to every peer, theirs into their places (one grouped operation).  A rank whose packing failed still
+    //      takes part (its peers are about to post their receives: the bytes it sends are then not its blocks, and it says so below)
     if (world > 1) {
         NCCLOK(ncclGroupStart());
         ncclResult_t gr = ncclSuccess;                                   // (a failed call inside the group still closes it)
@@ -182,6 +224,7 @@ int lzf_frame_gather(lzf_dist_comm* comm, const lzf_job_result* d_results, const
         if (gr != ncclSuccess) return fail(LZF_E_HIP, "ncclSend / ncclRecv", ncclGetErrorString(gr));
         if (ge != ncclSuccess) return fail(LZF_E_HIP, "ncclGroupEnd", ncclGetErrorString(ge));
     }
+    if (pack_rc != LZF_OK) return fail(pack_rc, "lzf_frame_gather", "packing this rank's segment failed");
     HIPOK(hipMemcpyAsync(d_frame, header, header_len, hipMemcpyHostToDevice, st));
     HIPOK(hipMemsetAsync(d_frame + flen - 4u, 0, 4u, st));           // EndMark (compress.rs:277)
     HIPOK(hipStreamSynchronize(st));

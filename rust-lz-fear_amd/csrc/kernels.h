@@ -114,6 +114,7 @@ struct seg_ctx {
 // decoder state a job's pieces hand on: flag = pieces finished so far (piece p starts when it reads p), kFedEnded once the job needs no more
 struct fed_state { uint32_t flag, cstart, expect, o; };
 constexpr uint32_t kFedEnded = 0x80000000u;
+constexpr uint32_t kFedTicketStride = 32u;      // (a counter per 128-byte line)
 struct fed_args {
     const lzf_decompress_job* jobs;
     lzf_job_result* results;
@@ -122,10 +123,11 @@ struct fed_args {
     const uint32_t* vfrom;       // seg_ctx::vfrom
     const uint32_t* perm;        // launch order: rank -> job (optional)
     fed_state* state;            // [n_jobs]
-    uint32_t* ticket;            // the launch's ticket counter
+    uint32_t* ticket;            // the launch's ticket counters, one per XCD, kFedTicketStride words apart
+    uint32_t xcc_mask;           // the XCDs the kernel's wavefronts run on (census): bit i = HW_REG_XCC_ID i
     uint32_t n_jobs, maxch;
     uint32_t pieces;             // every job goes through the kernel in this many pieces (1: whole)
-    uint32_t* census;            // not null: the launch only counts how many of its workgroups the device holds at once ([0] arrivals, [1] the answer)
+    uint32_t* census;            // not null: the launch only counts how many of its workgroups the device holds at once ([0] arrivals, [1] the answer, [2] mask of their XCDs)
 };
 __global__ void lzf_fed_reset_kernel(fed_args a);
 // X(name, ring bytes, bit-map words per round, token-list entries)

@@ -169,8 +169,9 @@ __global__ __launch_bounds__(64) void lzf_compress_compact_kernel(
         auto insert_from_lane = [&](uint32_t qi, uint32_t q, uint32_t h) {
             const uint32_t a16 = tab_a + 2u * h, pa = tab_a + 4u * (kParBase + (h >> 5)), bit = 1u << (h & 31u);
             const uint32_t val = bit & (0u - ((q >> 16) & 1u));
-            asm volatile("s_mov_b64 exec, %0\n\tds_write_b16 %1, %2\n\tds_mskor_b32 %3, %4, %5\n\ts_mov_b64 exec, -1"
-                         ::"s"(1ull << qi), "v"(a16), "v"(q), "v"(pa), "v"(bit), "v"(val) : "memory");
+            unsigned long long sv;      // (the incoming EXEC saved and restored, not assumed to be all lanes: ADVICE r5)
+            asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, %1\n\tds_write_b16 %2, %3\n\tds_mskor_b32 %4, %5, %6\n\ts_mov_b64 exec, %0"
+                         : "=&s"(sv) : "s"(1ull << qi), "v"(a16), "v"(q), "v"(pa), "v"(bit), "v"(val) : "memory");
         };
 #ifdef LZF_PHASE_TIMING
         long long tq = clock64();

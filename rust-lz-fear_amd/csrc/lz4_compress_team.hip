@@ -11,7 +11,11 @@ static_assert(team::kLdsWords * 4u == 163840u, "capi.hip's kTeamLds (the dispatc
 
 __global__ __launch_bounds__(192) void lzf_compress_team_kernel(const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results,
                                                                 uint32_t n_jobs, const uint32_t* __restrict__ perm, uint32_t alone) {
-    __shared__ __attribute__((aligned(16))) uint32_t lds[team::kLdsWords];
+    // aligned(16384): hash5_slot_addr (lzf_simt.h) ORs a slot's offset into the table's address, which is only an addition while the
+    // table (at byte 0x24000 of this array) starts on a 16 KiB boundary; a second __shared__ object in front of this one would break
+    // that silently — hence the alignment AND the check (the emulator adds, so the CPU suite cannot see it)
+    __shared__ __attribute__((aligned(16384))) uint32_t lds[team::kLdsWords];
+    if ((lds_addr(lds) & 0x3FFFu) != 0u) __builtin_trap();
     const SimtGpu b{lds, lds_addr(lds)};
     const team::Args a{jobs, results, n_jobs, perm, alone};
     team::compress_team(b, a, blockIdx.x);

@@ -19,6 +19,11 @@
 
 namespace lzf {
 
+// the XCD this wavefront runs on (0..7 on MI355X)
+__device__ __forceinline__ uint32_t xcc_id() {
+    uint32_t v; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(v)); return v & 15u;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // The launch is a fixed set of SLOTS — as many wavefronts as the device holds at once (capi.hip counts them) — that share the
 // jobs out in PIECES instead of one workgroup per job.  With one workgroup per job a launch of 2.2 jobs per slot takes three
@@ -28,7 +33,11 @@ namespace lzf {
 // t % n in launch order — lap after lap over all jobs, so all of them advance together and end together, and a slot that gets
 // cheap pieces simply draws more tickets.  A piece starts from the decoder state the piece before it parked (next round, chain
 // carry, output position; the ring is re-filled from `out`) and waits for it if it has to: it was drawn n tickets earlier, and
-// a launch has more jobs than slots, so as a rule it is long done.  Cost: a release / acquire pair and 4 KiB of ring per piece.
+// a launch has more jobs than slots, so as a rule it is long done.
+// Hand-overs stay inside one XCD: the wavefronts read which XCD they run on (HW_REG_XCC_ID) and every XCD has its own ticket
+// counter over its own share of the jobs (rank % number of XCDs).  What a piece wrote is then in the L2 its successor reads
+// through — a wait for the stores and an L1 invalidate are the whole hand-over.  Across XCDs it would take a write-back of the
+// writer's whole L2 (buffer_wbl2: measured ~150 us of the wave per hand-over, 98 -> 115 ms per call at 64 pieces per job).
 // ---------------------------------------------------------------------------------------------------------------------
 template <int RING, int W, int TOKCAP>
 __global__ __launch_bounds__(64) void lzf_decompress_fed_kernel(fed_args a) {
@@ -43,7 +52,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_fed_kernel(fed_args a) {
     static_assert(kCB % 16 == 0, "the round is staged in 16-byte pieces");
     __shared__ __attribute__((aligned(16))) uint8_t ring[RING];
     __shared__ __attribute__((aligned(16))) uint8_t cbuf[kCB];
-    __shared__ __attribute__((aligned(16))) uint32_t toks[TOKCAP + 64];
+    __shared__ __attribute__((aligned(16))) uint32_t toks[TOKCAP];
 
     const uint32_t lane = threadIdx.x;
     if (a.census) {
@@ -52,6 +61,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_fed_kernel(fed_args a) {
         // is the answer.  (The schedule needs the true number: a slot that starts late finishes late, and the slot that waits for
         // its hand-over with it.)
         if (lane == 0u) {
+            __hip_atomic_fetch_or(&a.census[2], 1u << (xcc_id() & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ... and on which XCDs they run
             __hip_atomic_fetch_add(&a.census[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned long long t0 = wall_clock64();
             while (wall_clock64() - t0 < 30000ull) __builtin_amdgcn_s_sleep(16);
@@ -61,13 +71,19 @@ __global__ __launch_bounds__(64) void lzf_decompress_fed_kernel(fed_args a) {
         return;
     }
     const uint32_t n = a.n_jobs, pieces = a.pieces;
-    const uint32_t n_tickets = n * pieces;
+    // this wavefront's XCD -> its group of jobs (ranks g, g + ng, g + 2 ng, ...) and that group's ticket counter
+    // (whole jobs need no hand-over: one group, one counter)
+    const uint32_t xcc = xcc_id() & 31u;
+    if (pieces > 1u && !((a.xcc_mask >> xcc) & 1u)) return;           // (an XCD the census did not see: no jobs were given to it)
+    const uint32_t ng = pieces > 1u ? (uint32_t)__popc(a.xcc_mask) : 1u, g = pieces > 1u ? (uint32_t)__popc(a.xcc_mask & ((1u << xcc) - 1u)) : 0u;
+    const uint32_t n_g = n > g ? (n - g + ng - 1u) / ng : 0u;
+    const uint32_t n_tickets = n_g * pieces;
     for (;;) {
     uint32_t tk = 0;
-    if (lane == 0u) tk = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0u) tk = __hip_atomic_fetch_add(a.ticket + g * kFedTicketStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     tk = __builtin_amdgcn_readfirstlane(tk);
     if (tk >= n_tickets) break;
-    const uint32_t piece = tk / n, k = tk - piece * n;
+    const uint32_t piece = tk / n_g, k = (tk - piece * n_g) * ng + g;
     const uint32_t jid = a.perm ? a.perm[k] : k;
     const seg_job sj = a.st[jid];
     if (!sj.eligible || sj.failed || sj.done) continue;
@@ -138,7 +154,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_fed_kernel(fed_args a) {
             }
             f = __builtin_amdgcn_readfirstlane(f);
             if (f != piece) continue;        // the job ended in an earlier piece (kFedEnded), or that piece never came: the pair kernel looks at what is left
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");       // (this compute unit's L1 may hold lines of `out` from an earlier piece of the job)
             cstart = fs->cstart; expect = fs->expect; o = fs->o;
         }
         uint32_t safe = o;   // out[0, safe) is visible to this wave's global loads
@@ -158,7 +174,11 @@ __global__ __launch_bounds__(64) void lzf_decompress_fed_kernel(fed_args a) {
             if (Tc) {
 #define LZF_TOKEN_AT(i) (toks[(i)] & 0xFFFFu)
 #define LZF_TOKEN_WORD(i) toks[(i)]
+#ifdef LZF_FED_FAR_LATE
+#define LZF_FAR_LATE
+#endif
 #include "lz4_decompress_batch_phase.inc"
+#undef LZF_FAR_LATE
 #undef LZF_TOKEN_WORD
 #undef LZF_TOKEN_AT
             }
@@ -175,7 +195,8 @@ __global__ __launch_bounds__(64) void lzf_decompress_fed_kernel(fed_args a) {
         if (parked && status == LZF_OK && !bailed) {
             // hand the job on: what this wave wrote must be visible to another compute unit before the flag is
             if (lane == 0u) { fs->cstart = cstart; fs->expect = expect; fs->o = o; }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            // (no release fence: the next piece runs on this XCD and reads through the same L2 — the stores only have to have arrived there)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (lane == 0u) __hip_atomic_store(&fs->flag, piece + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             continue;
@@ -201,7 +222,7 @@ __global__ __launch_bounds__(64) void lzf_decompress_fed_kernel(fed_args a) {
 // Before the launch: every job's hand-over flag and the ticket counter cleared.
 __global__ __launch_bounds__(256) void lzf_fed_reset_kernel(fed_args a) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0u) *a.ticket = 0u;
+    if (k < 32u) a.ticket[k * kFedTicketStride] = 0u;
     if (k < a.n_jobs) a.state[k].flag = 0u;
 }
 

@@ -859,6 +859,7 @@ __global__ __launch_bounds__(64) void lzf_seg_records_kernel(seg_ctx c) {
 __global__ __launch_bounds__(1024) void lzf_seg_by_len_kernel(seg_ctx c) {
     __shared__ uint32_t cost[1024];
     const uint32_t i = threadIdx.x, n = c.n_jobs;
+    if (n > 1024u) return;                                        // (one workgroup ranks the call: the dispatch never asks for more, capi.hip kSegRankMax)
     if (i < n) { const uint64_t l = c.jobs[i].input_len; cost[i] = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l; }
     __syncthreads();
     if (i >= n) return;
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(1024) void lzf_seg_by_len_kernel(seg_ctx c) {
     for (uint32_t k = 0; k < n; ++k) { const uint32_t o = cost[k]; r += (o > mine || (o == mine && k < i)) ? 1u : 0u; }
     c.by_len[r] = i;
 }
-// Grouped calls: one wavefront that does nothing for `ticks` of the 100 MHz clock.  It sits on the caller's stream between a group's
+// Grouped calls: one wavefront that does nothing for `ticks` of the device's wall clock (capi.hip converts from microseconds by the rate the runtime reports).  It sits on the caller's stream between a group's
 // records stage and the next one's: the group's resolve stage starts on another stream (an event away: a few microseconds later), and
 // its workgroups — 32+ KiB of LDS each — should find the compute units empty rather than squeeze in between the next records stage's
 // (measured at 980 blocks: 15.4 ms with such a pause, 17.0 without).
@@ -882,6 +883,7 @@ __global__ __launch_bounds__(64) void lzf_seg_pause_kernel(uint32_t ticks) {
 __global__ __launch_bounds__(1024) void lzf_seg_rank_kernel(seg_ctx c, uint32_t* __restrict__ by_tok, uint4 gs) {
     __shared__ uint32_t cost[1024];
     const uint32_t i = threadIdx.x, n = c.n_jobs;
+    if (n > 1024u) return;
     if (i < n) { const seg_job s = c.st[i]; cost[i] = (s.eligible && !s.failed) ? s.ntok : 0u; }
     __syncthreads();
     if (i >= n) return;
@@ -903,6 +905,7 @@ __global__ __launch_bounds__(1024) void lzf_seg_rank_kernel(seg_ctx c, uint32_t*
 __global__ __launch_bounds__(1024) void lzf_seg_order_kernel(seg_ctx c) {
     __shared__ uint32_t cost[1024];
     const uint32_t i = threadIdx.x, n = c.g_n;                     // (the ranks of this launch's group)
+    if (n > 1024u) return;
     const uint32_t job = i < n ? (c.grouped ? seg_job_of(c, i) : i) : 0u;
     if (i < n) { const seg_job s = c.st[job]; cost[i] = (s.eligible && !s.failed) ? s.ntok : 0u; }
     __syncthreads();

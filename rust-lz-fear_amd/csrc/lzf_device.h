@@ -1,6 +1,6 @@
 // lzf_device.h — shared device-side helpers for the gfx950 LZ4 kernels (wave64 only).
 #pragma once
-#if !defined(LZF_ANALYSIS) && (defined(LZF_DBG_SKIP) || defined(LZF_DBG_SKIP2) || defined(LZF_DBG_TIME) || defined(LZF_DBG_COUNT) || defined(LZF_DBG_DRY_MAIN) || defined(LZF_DBG_LDS_PAD) || defined(LZF_DBG_PATHS) || defined(LZF_DBG_PHASE_SEL) || defined(LZF_DBG_ROUNDS) || defined(LZF_DBG_TIMELINE) || \
+#if !defined(LZF_ANALYSIS) && (defined(LZF_DBG_SKIP) || defined(LZF_DBG_SKIP2) || defined(LZF_DBG_TIME) || defined(LZF_DBG_COUNT) || defined(LZF_DBG_DRY_MAIN) || defined(LZF_DBG_LDS_PAD) || defined(LZF_DBG_PATHS) || defined(LZF_DBG_PHASE_SEL) || defined(LZF_DBG_ROUNDS) || defined(LZF_DBG_TIMELINE) || defined(LZF_DBG_NOFENCE) || \
     defined(LZF_SEG_DBG_SKIP) || defined(LZF_SEG_DBG_NOWAIT) || defined(LZF_SEG_TIME) || defined(LZF_SEG_NOASM) || defined(LZF_SEG_NORLE))
 #error "LZF_DBG_* / LZF_SEG_* instrumentation is for -DLZF_ANALYSIS builds only"
 #endif

@@ -1,4 +1,4 @@
-// lzf_simt.h — the handful of wave-level primitives the row-mapped compress kernel (analysis/lz4_compress_rows.inc) is written in.
+// lzf_simt.h — the handful of wave-level primitives the team compress kernel (lz4_compress_team.inc: searcher / emitter / feeder) is written in.
 //
 // The kernel body is per-lane code with WAVE-UNIFORM control flow around every cross-lane operation: all 64 lanes call
 // every primitive below, in the same order, with a per-lane predicate.  Two backends:
@@ -94,7 +94,8 @@ struct SimtGpu {
                      : "=&v"(v0), "=&v"(v1), "=&v"(v2) : "v"(lds_a + b0), "v"(lds_a + b1), "v"(lds_a + b2) : "memory");
     }
     // LDS byte ADDRESS of the U32Table slot of the 8 bytes v8 (mod.rs:41-51; the arithmetic of simt_hash5), the table at the 16 KiB-aligned
-    // address tab_addr (a VGPR: VOP3 takes one scalar operand on gfx9): the slot's byte offset is bits 26..39 of v * K with the low two cleared
+    // address tab_addr (a VGPR: VOP3 takes one scalar operand on gfx9): the slot's byte offset is bits 26..39 of v * K with the low two cleared,
+    // OR-ed into tab_addr — which is why the kernel's LDS array is declared aligned(16384) and checks its base at entry
     LZF_SIMT_FN uint32_t hash5_slot_addr(uint64_t v8, uint32_t tab_addr) const {
         const uint32_t xl = (uint32_t)v8, xh = (uint32_t)(v8 >> 32);
         uint32_t t, u, r; uint64_t p;
@@ -115,8 +116,9 @@ struct SimtGpu {
     // lane 0 alone writes a 16-byte descriptor and, behind it, two adjacent flag words.  All 64 lanes must be active at the call
     // (the searcher's control flow is wave-uniform): EXEC is set to lane 0 and back to all lanes around the two stores.
     LZF_SIMT_FN void push16_flag2(uint32_t desc_byte, u32x4 d, uint32_t flag_byte, uint32_t f0, uint32_t f1) const {
-        asm volatile("s_mov_b64 exec, 1\n\tds_write_b128 %0, %1\n\tds_write_b64 %2, %3\n\ts_mov_b64 exec, -1"
-                     ::"v"(lds_a + desc_byte), "v"(d), "v"(lds_a + flag_byte), "v"(((uint64_t)f1 << 32) | f0) : "memory");
+        unsigned long long sv;      // (the incoming EXEC saved and restored, not assumed to be all lanes: ADVICE r5)
+        asm volatile("s_mov_b64 %0, exec\n\ts_mov_b64 exec, 1\n\tds_write_b128 %1, %2\n\tds_write_b64 %3, %4\n\ts_mov_b64 exec, %0"
+                     : "=&s"(sv) : "v"(lds_a + desc_byte), "v"(d), "v"(lds_a + flag_byte), "v"(((uint64_t)f1 << 32) | f0) : "memory");
     }
     // compare masks as scalars (v_cmp writes the lane mask directly; a ballot of a bool goes through a vector register and back), the first
     // set lane of a mask bounded from above in two scalar instructions (s_ff1 gives 0xFFFFFFFF for an empty mask), and a predicated

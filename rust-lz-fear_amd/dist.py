@@ -180,10 +180,26 @@ def dist_lib():
         L.lzf_dist_comm_init.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
         L.lzf_dist_comm_count.argtypes = [C.c_void_p]
         L.lzf_dist_comm_free.argtypes = [C.c_void_p]
+        L.lzf_dist_rccl_path.restype = C.c_char_p
         L.lzf_frame_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64,
                                        C.c_char_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p]
         _dist_lib = L
     return _dist_lib
+
+
+def rccl_paths():
+    """Which librccl the exchange library's calls resolve to (dladdr inside liblzfear_dist.so) and every librccl mapped into this
+    process (/proc/self/maps: torch carries its own copy) — bench.py prints both, so a run shows whether they are the same file."""
+    mine = dist_lib().lzf_dist_rccl_path().decode()
+    mapped = set()
+    try:
+        for line in open("/proc/self/maps"):
+            f = line.rstrip("\n").split(None, 5)
+            if len(f) == 6 and "librccl" in f[5]:
+                mapped.add(f[5])
+    except OSError:
+        pass
+    return {"liblzfear_dist_binds": mine, "mapped_in_process": sorted(mapped), "single_copy": len(mapped) <= 1}
 
 
 class DistComm:
@@ -193,14 +209,22 @@ class DistComm:
     def __init__(self, dist_mod, rank, world, device):
         L = dist_lib()
         uid = C.create_string_buffer(128)
+        rc0, err0 = 0, ""
         if rank == 0:
-            rc = L.lzf_dist_unique_id(uid)
-            if rc != 0:
-                raise ffi.LzfError(rc, L.lzf_dist_last_error().decode())
+            rc0 = L.lzf_dist_unique_id(uid)
+            if rc0 != 0:
+                err0 = L.lzf_dist_last_error().decode()
         if world > 1:
-            t = torch.frombuffer(bytearray(uid.raw), dtype=torch.uint8).to(device)
+            # rank 0's outcome travels WITH the id (byte 128): a failure there must not leave the other ranks in the broadcast
+            # (ADVICE r5), every rank raises instead
+            t = torch.frombuffer(bytearray(uid.raw) + bytearray([1 if rc0 == 0 else 0]), dtype=torch.uint8).to(device)
             dist_mod.broadcast(t, src=0)
-            uid = C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128)
+            got = bytes(t.cpu().numpy().tobytes())
+            uid = C.create_string_buffer(got[:128], 128)
+            if got[128] != 1:
+                raise ffi.LzfError(rc0 or ffi.E_HIP, "lzf_dist_unique_id failed on rank 0" + (": " + err0 if err0 else ""))
+        elif rc0 != 0:
+            raise ffi.LzfError(rc0, err0)
         self.handle = C.c_void_p()
         rc = L.lzf_dist_comm_init(uid, rank, world, C.byref(self.handle))
         if rc != 0:

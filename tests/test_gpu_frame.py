@@ -434,10 +434,53 @@ def test_frame_gather_c_abi_rccl_world1():
             lzdist.gather_frame_device_c(comm, d_res, d_out, d_in, BS, n, n, frame[:1000], header, last_block_len=int(blocks.lens[-1]))
         bad = res.copy(); bad["status"][1] = ffi.CONTRACT
         d_bad = device.to_device(bad, "cuda")
-        with pytest.raises(ffi.LzfError):
+        with pytest.raises(ffi.LzfError) as ei:
             lzdist.gather_frame_device_c(comm, d_bad, d_out, d_in, BS, n, n, frame, header, last_block_len=int(blocks.lens[-1]))
+        assert ei.value.code == ffi.CONTRACT
+        # a header that announces a content checksum (or block checksums): the frame this call writes carries neither
+        for kw in (dict(content_checksum=True), dict(block_checksums=True)):
+            with pytest.raises(ffi.LzfError) as ei:
+                lzdist.gather_frame_device_c(comm, d_res, d_out, d_in, BS, n, n, frame, lzdist.frame_header(block_size=BS, **kw), last_block_len=int(blocks.lens[-1]))
+            assert ei.value.code == ffi.E_INVALID
+        # ... and the library says which librccl it is bound to
+        assert "rccl" in lzdist.rccl_paths()["liblzfear_dist_binds"]
     finally:
         comm.close()
+
+
+def test_frame_gather_c_abi_rccl_world2():
+    """lzf_frame_gather with two ranks over RCCL (tests/dist_world2_check.py: one process per GPU): 7 and 8 blocks, a stored block, a
+    short last block, fewer blocks than ranks (a rank with no block at all), 2 W + 1 blocks — the whole frame == the oracle's on every
+    rank — and failures that only ONE rank can see (a block status that cannot be framed, a frame buffer that is too small, a header
+    that announces a checksum): every rank returns the same code, none is left in the exchange, the communicator works afterwards.
+    Needs two GPUs: skipped on the one-GPU box, runs on the driver's multi-GPU node."""
+    import socket
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs at least two GPUs (one process per GPU over RCCL)")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    world = 2
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(os.path.dirname(__file__), "dist_world2_check.py")], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("a rank of the two-rank exchange did not return (a hang is exactly what this test is for)")
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}:\n{out[-4000:]}"
+    assert "world2 ok" in outs[0]
 
 
 # ---------------------------------------------------------------- many frames per call
@@ -674,6 +717,43 @@ def test_examples_dolz4_delz4_round_trip(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "delz4.py"), str(lz), str(back)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert back.read_bytes() == data
+
+
+def test_examples_stream_a_file_larger_than_the_memory_budget(tmp_path):
+    """The drivers stream like the originals (examples/dolz4.rs:10-17: File -> File through compress_with_size; examples/delz4.rs:31-38:
+    fill_buf / consume): a 64 MiB file with the device-memory budget of the frame layer set to 16 MiB — four times smaller — goes
+    through dolz4 (4 MiB pieces into the frame writer) and delz4 (four blocks read ahead) with the Python side never holding more than
+    a fraction of the file (tracemalloc peak), the .lz4 is the oracle's frame and the round trip is exact."""
+    import importlib.util
+    import tracemalloc
+    from rust_lz_fear_amd import ffi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(root, "tools", name + ".py"))
+        m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+        return m
+    dolz4, delz4 = load("dolz4"), load("delz4")
+    total = 64 << 20
+    data = synth.silesia_mix(0, total).tobytes()
+    src = tmp_path / "big.bin"; src.write_bytes(data)
+    lz = tmp_path / "big.bin.lz4"; back = tmp_path / "big.back"
+    want = o.frame_compress(data, o.make_settings(content_size=len(data)))[1]
+    del data
+    ffi.lib().lzf_frame_set_memory_budget(16 << 20)
+    try:
+        tracemalloc.start()
+        n_in, n_out = dolz4.compress_file(framed.CompressionSettings(), str(src), str(lz), with_size=True, piece=4 << 20)
+        peak_c = tracemalloc.get_traced_memory()[1]; tracemalloc.reset_peak()
+        m_in, m_out = delz4.decompress_file(str(lz), str(back), readahead=4)
+        peak_d = tracemalloc.get_traced_memory()[1]
+        tracemalloc.stop()
+    finally:
+        ffi.lib().lzf_frame_set_memory_budget(0)
+    assert (n_in, m_out) == (total, total) and n_out == m_in == len(want)
+    assert lz.read_bytes() == want
+    assert back.read_bytes() == src.read_bytes()
+    assert peak_c < total // 2 and peak_d < total // 2, (peak_c, peak_d)      # bounded by pieces / blocks in flight, not by the file
 
 
 @pytest.mark.parametrize("kw", [dict(block_size=64 << 10, block_checksums=True), dict(block_size=64 << 10, dictionary=synth.gen_text_zipf(21, 5000).tobytes(), dictionary_id=5)])

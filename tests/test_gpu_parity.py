@@ -165,14 +165,17 @@ def _analysis_env(**kw):
     return dict(os.environ, LZF_LIB_PATH=path, **kw)
 
 
-@pytest.mark.parametrize("variant", ["auto", "wave", "staged16", "staged32", "direct4w", "paired16", "paired24", "paired48", "paired256", "seg", "ordered"])
+@pytest.mark.parametrize("variant", ["auto", "wave", "staged16", "staged32", "direct4w", "paired16", "paired24", "paired48", "paired256", "seg", "fed", "fed3", "ordered"])
 def test_every_decompress_kernel_generation(variant):
     """Every kernel generation kept in the analysis library (and every ring/region geometry) implements the same contract.
     "ordered": the longest-first launch order that large batches get, forced on for these small ones.
     "seg": the segmented pipeline (one block decoded by many wavefronts) with its size window opened to every input — small
-    blocks, handcrafted streams; malformed, prefix and existing-output jobs take its hand-over to the pair kernel."""
+    blocks, handcrafted streams; malformed, prefix and existing-output jobs take its hand-over to the pair kernel.
+    "fed" / "fed3": the bitmap-fed kernel of large batches (round 6) forced for these small ones, whole jobs / every job in three pieces."""
     import subprocess, sys
     env = _analysis_env(LZF_DECOMPRESS_KERNEL=variant) if variant != "ordered" else _analysis_env(LZF_DECOMPRESS_ORDER="always")
+    if variant.startswith("fed"):       # the bitmap-fed kernel for every batch size and input size; "fed3": every job handed on twice (three pieces)
+        env = _analysis_env(LZF_DECOMPRESS_KERNEL="fed", LZF_FED_MIN_IN="1", **({"LZF_FED_PIECES": "3"} if variant == "fed3" else {}))
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(__file__), "variant_check.py")], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -195,8 +198,8 @@ def test_every_compress_kernel(kernel):
 
 
 def test_product_dispatch_every_batch_size_class():
-    """The product library has no knobs: the batch size alone picks the kernel (decompress: paired48 up to 8 blocks per CU, paired24
-    up to 64 per CU, staged16 beyond; compress: the team kernel up to one block per CU, the compact kernel beyond) and the launch
+    """The product library has no knobs: the batch size alone picks the kernel (decompress: the segmented pipeline up to 4 blocks per CU,
+    paired48 up to 8, the bitmap-fed kernel beyond — paired24 / staged16 when it declines a call; compress: the team kernel up to one block per CU, the compact kernel beyond) and the launch
     order (longest first beyond 8 blocks per CU for decompress, beyond 18 per CU for compress).  Batches on both sides of every threshold, small blocks so the oracle keeps up."""
     rng = np.random.default_rng(5)
     base = synth.silesia_mix(0, 1 << 20)
