@@ -1,5 +1,5 @@
 #!/bin/bash
-# A/B of compress-kernel builds in bench.py's own setting (240 copies with distinct inputs): tools/gpu_bench_compress_ab.sh <lib.so> ...
+# A/B of compress-kernel builds in bench.py's own setting (240 copies with distinct inputs): profiles/leases/gpu_bench_compress_ab.sh <lib.so> ...
 mkdir -p gpurun_out/r05; L=gpurun_out/r05/bench_compress_ab.log; rm -f $L
 for lib in "$@"; do
   echo "== $lib" >> $L

@@ -1,4 +1,4 @@
-# TA / TD / TCP counters of the decompress kernel in separate rocprofv3 --pmc passes: bash tools/run_pmc_tcp.sh [lib.so]
+# TA / TD / TCP counters of the decompress kernel in separate rocprofv3 --pmc passes: bash profiles/leases/run_pmc_tcp.sh [lib.so]
 set -u
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/pmc3; cd /tmp; export TMPDIR=/tmp
 LIB=${1:-$R/dbg/lib_full.so}

@@ -1,4 +1,4 @@
-# usage: bash tools/run_pmc_variants.sh variant...   (dbg/lib_<variant>.so built with -DLZF_DBG_SKIP=...)
+# usage: bash profiles/leases/run_pmc_variants.sh variant...   (dbg/lib_<variant>.so built with -DLZF_DBG_SKIP=...)
 set -u
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/pmc2; cd /tmp; export TMPDIR=/tmp
 for v in "$@"; do

@@ -68,7 +68,7 @@ def assemble_frame(settings, payloads, comp_len, raw_len, content_xxh32):
     n = len(payloads)
     host = [bytes(p.cpu().numpy().tobytes()) for p in payloads]
     bufs = [C.create_string_buffer(h, max(len(h), 1)) for h in host]
-    ptrs = (C.c_void_p * n)(*[C.cast(b, C.c_void_p) for b in bufs])
+    ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
     cl = (C.c_uint32 * n)(*[int(c) for c in comp_len])
     rl = (C.c_uint32 * n)(*[int(r) for r in raw_len])
     cap = 64 + sum(len(h) + 8 for h in host)

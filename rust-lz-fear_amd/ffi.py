@@ -202,6 +202,13 @@ def xxh32_blocks_host(blocks):
     return list(out)
 
 
+def _bytes_address(b):
+    """Address of a bytes object's payload (read-only use; the caller keeps `b` alive).  No copy, and no ctypes.cast: cast() objects
+    reference themselves, so buffers hanging off them live until the cycle collector runs."""
+    cp = C.c_char_p(b)                            # (holds a reference to b and, in its own storage, the pointer)
+    return C.c_void_p.from_address(C.addressof(cp)).value
+
+
 def compress_blocks_host(items):
     """items: list of dict(input=bytes, cursor=int, kind=TABLE_*, table=None|U32Table|U16Table,
     out_cap=int, readonly=bool).  Returns list of (status, bytes)."""
@@ -219,17 +226,17 @@ def compress_blocks_host(items):
         ib = C.create_string_buffer(data, max(len(data), 1))
         ob = C.create_string_buffer(max(cap, 1))
         keep.append((ib, ob))
-        jobs[i].input = C.cast(ib, C.c_void_p)
+        jobs[i].input = C.addressof(ib)
         jobs[i].input_len = len(data)
         jobs[i].cursor = it.get("cursor", 0)
-        jobs[i].out = C.cast(ob, C.c_void_p)
+        jobs[i].out = C.addressof(ob)
         jobs[i].out_cap = cap
         t = it.get("table")
         jobs[i].table = C.addressof(t) if t is not None else None
         jobs[i].table_kind = it.get("kind", TABLE_U32)
         jobs[i].flags = CJOB_TABLE_READONLY if it.get("readonly") else 0
     check(lib().lzf_compress_batch_host(jobs, res, n))
-    return [(res[i].status, keep[i][1].raw[: res[i].out_len] if res[i].status == OK else b"") for i in range(n)]
+    return [(res[i].status, C.string_at(keep[i][1], res[i].out_len) if res[i].status == OK else b"") for i in range(n)]
 
 
 def decompress_blocks_host(items):
@@ -251,16 +258,14 @@ def decompress_blocks_host(items):
         cap = it.get("out_cap")
         if cap is None:
             cap = len(existing) + min(limit, 1 << 26) + len(data) + 64
-        ib = C.create_string_buffer(data, max(len(data), 1))
-        pb = C.create_string_buffer(prefix, max(len(prefix), 1))
         ob = C.create_string_buffer(max(cap, 1))
         ob[: len(existing)] = existing
-        keep.append((ib, pb, ob))
-        jobs[i].input = C.cast(ib, C.c_void_p)
+        keep.append((data, prefix, ob))          # (the bytes objects themselves are the inputs: no staging copy on this side)
+        jobs[i].input = _bytes_address(data)
         jobs[i].input_len = len(data)
-        jobs[i].prefix = C.cast(pb, C.c_void_p)
+        jobs[i].prefix = _bytes_address(prefix)
         jobs[i].prefix_len = len(prefix)
-        jobs[i].out = C.cast(ob, C.c_void_p)
+        jobs[i].out = C.addressof(ob)
         jobs[i].out_existing_len = len(existing)
         jobs[i].out_cap = cap
         jobs[i].output_limit = limit
@@ -268,5 +273,6 @@ def decompress_blocks_host(items):
     out = []
     for i in range(n):
         ln = min(res[i].out_len, jobs[i].out_cap)
-        out.append((res[i].status, keep[i][2].raw[:ln]))
+        out.append((res[i].status, C.string_at(keep[i][2], ln)))
+        keep[i] = None                           # a block's staging buffer goes as soon as its bytes are out (streaming readers: memory = blocks in flight)
     return out

@@ -118,7 +118,7 @@ class CompressionSettings:
         keep = None
         if self._dictionary is not None:
             keep = C.create_string_buffer(self._dictionary, max(len(self._dictionary), 1))
-            s.dictionary = C.cast(keep, C.c_void_p)
+            s.dictionary = C.addressof(keep)
             s.dictionary_len = len(self._dictionary)
         if self._dictionary_id is not None:
             s.has_dictionary_id = 1
@@ -139,7 +139,7 @@ class CompressionSettings:
         ffi.check(rc)
         if rc != 0:
             raise FrameError(rc)
-        return out.raw[: n.value]
+        return C.string_at(out, n.value)
 
     def compress(self, data):                    # :137-140
         return self._run(data, None)
@@ -165,7 +165,7 @@ class CompressionSettings:
         outs = [C.create_string_buffer(max(c, 1)) for c in caps]
         ins = (C.c_char_p * n)(*datas)
         lens = (C.c_size_t * n)(*[len(d) for d in datas])
-        outp = (C.c_void_p * n)(*[C.cast(o, C.c_void_p) for o in outs])
+        outp = (C.c_void_p * n)(*[C.addressof(o) for o in outs])
         capa = (C.c_size_t * n)(*caps)
         olen = (C.c_size_t * n)()
         st = (C.c_int * n)()
@@ -173,7 +173,7 @@ class CompressionSettings:
         for f in range(n):
             if st[f] != 0:
                 raise FrameError(st[f])
-        return [outs[f].raw[: olen[f]] for f in range(n)]
+        return [C.string_at(outs[f], olen[f]) for f in range(n)]
 
     def compress_with_size(self, data):          # :147-157
         return self._run(data, len(data))
@@ -204,8 +204,8 @@ def decompress_frame(frame, dictionary=b"", cap=None):
     rc = ffi.lib().lzf_frame_decompress(frame, len(frame), dictionary, len(dictionary), out, cap, C.byref(n), C.byref(used))
     ffi.check(rc)
     if rc != 0:
-        raise FrameError(rc, out.raw[: n.value])
-    return out.raw[: n.value]
+        raise FrameError(rc, C.string_at(out, n.value))
+    return C.string_at(out, n.value)
 
 
 def decompress_frames(frames, dictionary=b"", caps=None, with_consumed=False):
@@ -222,15 +222,15 @@ def decompress_frames(frames, dictionary=b"", caps=None, with_consumed=False):
     outs = [C.create_string_buffer(c) for c in caps]
     ins = (C.c_char_p * n)(*frames)
     lens = (C.c_size_t * n)(*[len(f) for f in frames])
-    outp = (C.c_void_p * n)(*[C.cast(o, C.c_void_p) for o in outs])
+    outp = (C.c_void_p * n)(*[C.addressof(o) for o in outs])
     capa = (C.c_size_t * n)(*caps)
     olen = (C.c_size_t * n)()
     used = (C.c_size_t * n)()
     st = (C.c_int * n)()
     ffi.check(ffi.lib().lzf_frame_decompress_many(n, ins, lens, dictionary, len(dictionary), outp, capa, olen, used, st))
     if with_consumed:
-        return [(st[f], outs[f].raw[: olen[f]], used[f]) for f in range(n)]
-    return [(st[f], outs[f].raw[: olen[f]]) for f in range(n)]
+        return [(st[f], C.string_at(outs[f], olen[f]), used[f]) for f in range(n)]
+    return [(st[f], C.string_at(outs[f], olen[f])) for f in range(n)]
 
 
 class FrameBlockReader:
@@ -255,7 +255,7 @@ class FrameBlockReader:
         ffi.check(rc)
         if rc != 0:
             raise FrameError(rc)
-        return self._buf.raw[: n.value]
+        return C.string_at(self._buf, n.value)
 
     def finished(self):
         return bool(ffi.lib().lzf_frame_reader_finished(self._h))
@@ -421,7 +421,7 @@ class LZ4FrameReader:
                 if self._csum:
                     ffi.lib().lzf_xxh32_update(C.byref(self._hasher), item, len(item))    # :276-278
                 self._buffer = item
-        return self._buffer[self._taken:]
+        return self._buffer[self._taken:] if self._taken else self._buffer      # (no copy of a block nobody has consumed from)
 
     def consume(self, amt):
         self._taken += amt

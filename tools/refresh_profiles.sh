@@ -1,15 +1,15 @@
 #!/bin/bash
 # Regenerates the round's measurement artifacts on the GPU box (run through gpurun from the repo root), product library only:
-#   gpurun_out/r05/bench_default.json          python bench.py (the driver's default invocation)
-#   gpurun_out/r05/kernel_stats.txt            rocprofv3 --kernel-trace --stats of the same command
-#   gpurun_out/r05/pmc_{FETCH,WRITE}_SIZE.txt  separate --pmc passes at 48 copies (1 step; 2352 compressed blocks: the same kernels
+#   gpurun_out/r06/bench_default.json          python bench.py (the driver's default invocation)
+#   gpurun_out/r06/kernel_stats.txt            rocprofv3 --kernel-trace --stats of the same command
+#   gpurun_out/r06/pmc_{FETCH,WRITE}_SIZE.txt  separate --pmc passes at 48 copies (1 step; 2352 compressed blocks: the same kernels
 #                                               as the default run — counter collection at 240 copies does not finish) for HBM traffic
-#   gpurun_out/r05/hbm_traffic.json            the two passes as the file bench.py reads (copy to profiles/r05_hbm_traffic.json)
-#   gpurun_out/r05/bench_config4.json          python bench.py --workload config4
-#   gpurun_out/r05/issue_counters.json         SQ instruction counters of both headline kernels per sequence (copy to profiles/r05_issue_counters.json)
-#   gpurun_out/r05/bench_config5.json          python bench.py --workload config5
+#   gpurun_out/r06/hbm_traffic.json            the two passes as the file bench.py reads (copy to profiles/r06_hbm_traffic.json)
+#   gpurun_out/r06/bench_config4.json          python bench.py --workload config4
+#   gpurun_out/r06/issue_counters.json         SQ instruction counters of both headline kernels per sequence (copy to profiles/r06_issue_counters.json)
+#   gpurun_out/r06/bench_config5.json          python bench.py --workload config5
 set -u
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05; rm -rf $O; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06; rm -rf $O; mkdir -p $O
 cd $R && timeout 1500 python bench.py > $O/bench_default.log 2>&1; grep '^{"metric"' $O/bench_default.log | tail -1 > $O/bench_default.json
 cd /tmp; export TMPDIR=/tmp
 (cd $R && timeout 1500 rocprofv3 --kernel-trace --stats -d $O/prof -o x -- python bench.py --no-cpu --no-e2e --no-config4 --no-config5 > $O/prof.log 2>&1)
@@ -40,7 +40,7 @@ def per_dispatch(counter, needle):
             best = (p[1], float(p[5].split()[-1]), p[3].split()[-1])
     return best
 out = {"_what": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, with --kernel-trace) of `python bench.py --copies 48 --distinct 1 --steps 1 --warmup 0 --no-cpu --no-e2e --no-verify` "
-                "(48 copies: the same kernels as the default 240-copy run; bench.py scales by job count) on MI355X, round 5; per dispatch, in the counters' KB units (x1024 bytes). "
+                "(48 copies: the same kernels as the default 240-copy run; bench.py scales by job count) on MI355X, round 6; per dispatch, in the counters' KB units (x1024 bytes). "
                 "gfx950 correction (MI355X_MICROARCH.md, HBM section): FETCH_SIZE reports half of the bytes of wide streaming reads; bench.py uses 2 x FETCH + WRITE as the upper bound."}
 dk = line["roofline"]["kernel"].replace(",", ", ")        # the launched variant exactly, as rocprofv3 prints it (the batch sweep launches others)
 for which, needle, jobs in (("decompress", dk, line["kernel_only"]["blocks_per_gpu"]), ("compress", "lzf_compress_compact_kernel<false>", line["config"]["blocks_per_gpu"])):
@@ -67,7 +67,7 @@ for r in csv.DictReader(open(f)):
     if (k, r["Dispatch_Id"]) not in seen: seen.add((k, r["Dispatch_Id"])); cnt[k] += 1
 SEQ_PER_COPY = 11.71e6          # sequences of one copy of the corpus (oracle statistics, tools/seq_stats.c)
 out = {"_what": "rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES (one pass, with --kernel-trace) of "
-                "`python bench.py --copies 48 --distinct 1 --steps 1 --warmup 0 ...` on MI355X, round 5; wave-instructions per dispatch and per sequence "
+                "`python bench.py --copies 48 --distinct 1 --steps 1 --warmup 0 ...` on MI355X, round 6; wave-instructions per dispatch and per sequence "
                 "(48 copies x 11.71 M sequences)."}
 dk = line["roofline"]["kernel"].replace(",", ", ")
 for which, needle in (("decompress", dk), ("compress", "lzf_compress_compact_kernel<false>")):
