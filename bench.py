@@ -617,55 +617,75 @@ def run_silesia(args, torch, device, ffi, dist, rank, world, dev, bases):
 
 
 def end_to_end(bases, ffi):
-    """The C ABI from HOST buffers (lzfear_frame.h): 64 frames of 16 MiB per call, independent blocks, content checksum — at the
-    reference's default block size (4 MiB: 256 blocks per call, so both kernels run at single-block latency) and at 64 KiB
-    blocks (16384 blocks per call).  PCIe in and out, frame scan / assembly and checksums included — never the bench `value`."""
+    """The C ABI from HOST buffers (lzfear_frame.h): frames of 16 MiB, independent blocks, content checksum — at the reference's
+    default block size (4 MiB) and at 64 KiB blocks, 64 frames (1 GiB) per call; and, at 4 MiB blocks, the same calls at 4 GiB and
+    16 GiB per call (`call_size_sweep`: 256 blocks per call is exactly the one-block-per-CU latency class of both kernels, the larger
+    calls are the throughput class).  PCIe in and out, frame scan / assembly and checksums included — never the bench `value`."""
     from rust_lz_fear_amd import framed
     L = ffi.lib()
     F, fsz = 64, 16 << 20
     mix = bases[0]
-    datas = [mix[(i * fsz) % (mix.size - fsz):][:fsz].tobytes() for i in range(F)]
-    n = len(datas)
-    total = sum(len(d) for d in datas)
-    res = {"frames": n, "frame_bytes": fsz, "settings": "independent blocks, content checksum (CompressionSettings::default())",
-           "buffers": "pageable host memory", "calls": "median of 5 after one warm-up call (the first call pins the staging slab)"}
-    for bs, key in ((4 << 20, "4MiB_blocks"), (64 << 10, "64KiB_blocks")):
+    distinct = [mix[(i * fsz) % (mix.size - fsz):][:fsz].tobytes() for i in range(F)]
+    res = {"frames": F, "frame_bytes": fsz, "settings": "independent blocks, content checksum (CompressionSettings::default())",
+           "buffers": "pageable host memory", "calls": "median of 5 after one warm-up call (the first call pins the staging slab); the 4 and 16 GiB calls: median of 3 after one"}
+
+    def point(bs, n, reps):
+        datas = [distinct[i % F] for i in range(n)]                    # (inputs may repeat: every frame still has its own output buffer)
+        total = n * fsz
         s = framed.CompressionSettings().block_size(bs)._struct(None)
-        caps = [L.lzf_frame_compress_bound(C.byref(s), len(d)) for d in datas]
-        outs = [C.create_string_buffer(c) for c in caps]
+        cap = L.lzf_frame_compress_bound(C.byref(s), fsz)
+        outs = [C.create_string_buffer(cap) for _ in range(n)]
         ins = (C.c_char_p * n)(*datas)
-        lens = (C.c_size_t * n)(*[len(d) for d in datas])
-        outp = (C.c_void_p * n)(*[C.cast(o, C.c_void_p) for o in outs])
-        capa = (C.c_size_t * n)(*caps)
+        lens = (C.c_size_t * n)(*[fsz] * n)
+        outp = (C.c_void_p * n)(*[C.addressof(o) for o in outs])
+        capa = (C.c_size_t * n)(*[cap] * n)
         olen = (C.c_size_t * n)()
         st = (C.c_int * n)()
         tcs = []
-        for _ in range(6):
+        for _ in range(reps + 1):
             t = time.perf_counter()
             rc = L.lzf_frame_compress_many(C.byref(s), n, ins, lens, outp, capa, olen, st)
             tcs.append(time.perf_counter() - t)
             assert rc == 0 and not any(st)
-        frames = [outs[f].raw[: olen[f]] for f in range(n)]
-        dcap = [len(d) + 64 for d in datas]
-        douts = [C.create_string_buffer(c) for c in dcap]
+        frames = [C.string_at(outs[f], olen[f]) for f in range(n)]
+        del outs
+        dcap = fsz + 64
+        douts = [C.create_string_buffer(dcap) for _ in range(n)]
         fin = (C.c_char_p * n)(*frames)
         flen = (C.c_size_t * n)(*[len(f) for f in frames])
-        doutp = (C.c_void_p * n)(*[C.cast(o, C.c_void_p) for o in douts])
-        dcapa = (C.c_size_t * n)(*dcap)
+        doutp = (C.c_void_p * n)(*[C.addressof(o) for o in douts])
+        dcapa = (C.c_size_t * n)(*[dcap] * n)
         dlen = (C.c_size_t * n)()
         used = (C.c_size_t * n)()
         dst = (C.c_int * n)()
         tds = []
-        for _ in range(6):
+        for _ in range(reps + 1):
             t = time.perf_counter()
             rc = L.lzf_frame_decompress_many(n, fin, flen, None, 0, doutp, dcapa, dlen, used, dst)
             tds.append(time.perf_counter() - t)
             assert rc == 0 and not any(dst)
-        assert all(douts[f].raw[: dlen[f]] == datas[f] for f in range(0, n, 8))
-        res[key] = {"frame_compress_many_gibs": round(total / sorted(tcs[1:])[2] / 2**30, 3),
-                    "frame_decompress_many_gibs": round(total / sorted(tds[1:])[2] / 2**30, 3),
-                    "frame_compress_many_ms": round(sorted(tcs[1:])[2] * 1e3, 1), "frame_decompress_many_ms": round(sorted(tds[1:])[2] * 1e3, 1)}
-        del outs, douts
+        assert all(C.string_at(douts[f], dlen[f]) == datas[f] for f in range(0, n, max(8, n // 16)))
+        mc, md = sorted(tcs[1:])[len(tcs[1:]) // 2], sorted(tds[1:])[len(tds[1:]) // 2]
+        return {"frame_compress_many_gibs": round(total / mc / 2**30, 3), "frame_decompress_many_gibs": round(total / md / 2**30, 3),
+                "frame_compress_many_ms": round(mc * 1e3, 1), "frame_decompress_many_ms": round(md * 1e3, 1)}
+
+    for bs, key in ((4 << 20, "4MiB_blocks"), (64 << 10, "64KiB_blocks")):
+        res[key] = point(bs, F, 5)
+    sweep = {"1GiB": dict(res["4MiB_blocks"], blocks=F * 4)}
+    try:
+        avail = int([l.split()[1] for l in open("/proc/meminfo") if l.startswith("MemAvailable")][0]) * 1024
+    except Exception:
+        avail = 0
+    for gib in (4, 16):
+        n = gib * 64
+        if avail < 4 * gib * 2**30:                                    # frames + both sets of output buffers + the staging's own
+            sweep[f"{gib}GiB"] = {"skipped": f"{avail >> 30} GiB of host memory available"}
+            continue
+        try:
+            sweep[f"{gib}GiB"] = dict(point(4 << 20, n, 3), blocks=n * 4)
+        except Exception as e:                                          # (never the line: this leg is extra)
+            sweep[f"{gib}GiB"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    res["call_size_sweep"] = {"what": "4 MiB blocks, frames of 16 MiB, one lzf_frame_compress_many / lzf_frame_decompress_many call over 1 / 4 / 16 GiB of host memory", **sweep}
     L.lzf_frame_release_scratch()
     return res
 

@@ -460,23 +460,25 @@ void lzf_frame_set_host_threads(uint32_t n) {
 static int compress_many_pass(const lzf_settings* s, uint32_t n_frames, const uint8_t* const* in, const size_t* in_len,
                               uint8_t* const* out, const size_t* out_cap, size_t* out_len, int* status);
 
-// Pinned host memory and device memory of a call are bounded: the frames go through in passes of at most kPinnedMax input
-// bytes (and at most half the memory budget of lzf_frame_set_memory_budget / of the free HBM, at ~2.2 x the input per pass);
-// a single frame larger than that is a pass of its own.
-constexpr size_t kPinnedMax = (size_t)2 << 30;
+// Device memory of a call is bounded: the frames go through in passes of at most a third of the memory budget
+// (lzf_frame_set_memory_budget; by default half of the free HBM) of input bytes — input, output slots and the packed result
+// of a pass are on the device together; a single frame larger than that is a pass of its own.  Pinned host memory is bounded
+// by the staging itself (host_staging.cpp: the slab stops growing at 2 GiB and is recycled as a ring within a pass), so a pass
+// is as large as the device allows: until round 6 a pass was also capped at 2 GiB of pinned memory, and a 16 GiB call of 4 MiB
+// blocks went through as eight passes of 512 blocks — each of them in the single-block latency class of the compress kernel.
+constexpr size_t kSmallCall = (size_t)1 << 30;      // calls up to this size are one pass without asking the device
 
 int lzf_frame_compress_many(const lzf_settings* s, uint32_t n_frames, const uint8_t* const* in, const size_t* in_len,
                             uint8_t* const* out, const size_t* out_cap, size_t* out_len, int* status) {
     if (!s || (n_frames && (!in || !in_len || !out || !out_cap || !out_len || !status))) return LZF_E_INVALID;
     size_t total = 0;
     for (uint32_t f = 0; f < n_frames; ++f) total += in_len[f];
-    size_t limit = kPinnedMax;
-    if (total > limit / 2) {                                                    // (small calls skip the device query)
+    size_t limit = kSmallCall;
+    if (total > limit || g_budget) {                                            // (small calls skip the device query)
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-            const size_t budget = g_budget ? g_budget : free_b / 2;
-            if (budget / 3 < limit) limit = budget / 3;                         // input + output slots + packed result per pass
-        } else (void)hipGetLastError();
+        if (g_budget) limit = g_budget / 3;                                     // input + output slots + packed result per pass
+        else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) limit = free_b / 2 / 3;
+        else (void)hipGetLastError();
     }
     if (total <= limit) return compress_many_pass(s, n_frames, in, in_len, out, out_cap, out_len, status);
     for (uint32_t f0 = 0; f0 < n_frames;) {
@@ -1033,16 +1035,15 @@ int lzf_frame_decompress_many(uint32_t n_frames, const uint8_t* const* in, const
     if (n_frames == 0) return LZF_OK;
     Staging& sg = Staging::get();
     std::lock_guard<std::mutex> guard(sg.lock());
-    // ---- slices: as many frames per pass as the memory budget holds (half of what the device has free) and as kPinnedMax of
-    //      pinned host memory carries (a frame's bytes in, its decoded bytes out: the larger of the two sums is the slab);
-    //      a frame that does not fit the budget alone reports LZF_E_NO_MEMORY
+    // ---- slices: as many frames per pass as the memory budget holds (half of what the device has free; pinned host memory is
+    //      the staging's business: a ring of at most 2 GiB); a frame that does not fit the budget alone reports LZF_E_NO_MEMORY
     size_t free_b = 0, total_b = 0;
     HIPOK(hipMemGetInfo(&free_b, &total_b));
     size_t budget = g_budget ? g_budget : free_b / 2;
     for (uint32_t f0 = 0; f0 < n_frames;) {
-        size_t sum = 0, pin_in = 0, pin_out = 0; uint32_t f1 = f0;
-        while (f1 < n_frames && (f1 == f0 || (sum + fr[f1].need <= budget && pin_in + in_len[f1] <= kPinnedMax && pin_out + out_cap[f1] <= kPinnedMax))) {
-            sum += fr[f1].live ? fr[f1].need : 0; pin_in += in_len[f1]; pin_out += out_cap[f1]; ++f1;
+        size_t sum = 0; uint32_t f1 = f0;
+        while (f1 < n_frames && (f1 == f0 || sum + fr[f1].need <= budget)) {
+            sum += fr[f1].live ? fr[f1].need : 0; ++f1;
         }
         if (f1 == f0 + 1 && fr[f0].live && fr[f0].need > budget) {
             status[f0] = LZF_E_NO_MEMORY; out_len[f0] = 0; if (consumed) consumed[f0] = 0;

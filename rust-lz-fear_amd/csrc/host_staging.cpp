@@ -11,6 +11,7 @@ namespace lzf_host {
 namespace {
 constexpr size_t kPiece = 4u << 20;          // bytes per memcpy task / DMA: small enough to pipeline, large enough for full PCIe rate
 constexpr size_t kInline = 256u << 10;       // moves this small are done by the calling thread
+constexpr size_t kRingMax = (size_t)2 << 30; // the slab never grows beyond this: a larger move goes through it as a RING of kPiece slots
 inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // One task = consecutive pieces of segments whose slab range [a, b) is moved by one DMA.
@@ -125,6 +126,8 @@ void Staging::release() {
     for (auto& s : streams_) { if (s) (void)hipStreamDestroy(s); s = nullptr; }
     for (auto e : events_) (void)hipEventDestroy(e);
     events_.clear();
+    for (auto e : slot_ev_) if (e) (void)hipEventDestroy(e);
+    slot_ev_.clear(); slot_busy_.clear(); next_slot_ = 0;
     device_ = -1;
     (void)hipGetLastError();
 }
@@ -132,8 +135,9 @@ void Staging::release() {
 uint8_t* Staging::pinned(size_t bytes) {
     int dev = -1; if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     if (device_ != dev) { release(); device_ = dev; }
+    if (bytes > kRingMax) bytes = kRingMax;            // (a move larger than the slab recycles it slot by slot: upload / download)
     if (bytes <= pin_cap_ && pin_) return pin_;
-    if (pin_) { (void)hipHostFree(pin_); pin_ = nullptr; pin_cap_ = 0; }
+    if (pin_) { if (!drain_slots()) return nullptr; (void)hipHostFree(pin_); pin_ = nullptr; pin_cap_ = 0; }
     // (small calls pin little: 1 MiB steps below 16 MiB, 64 MiB steps beyond)
     const size_t cap = round_up(bytes ? bytes : 1, bytes < (16u << 20) ? (1u << 20) : (64u << 20));
     void* p = nullptr;
@@ -182,6 +186,35 @@ hipEvent_t Staging::event(size_t i) {
     return events_[i];
 }
 
+// ---- the slab as a ring of kPiece slots (moves larger than the slab) ----------------------------------------------------------
+// A slot is busy while an H2D copy out of it may still be in flight (uploads return when their copies are ISSUED); slot_ev_[s]
+// is recorded behind that copy.  D2H copies into a slot and the workers' memcpys are over when download() returns.
+bool Staging::slot_wait(size_t s) {
+    if (s < slot_busy_.size() && slot_busy_[s]) {
+        if (hipEventSynchronize(slot_ev_[s]) != hipSuccess) return false;
+        slot_busy_[s] = 0;
+    }
+    return true;
+}
+bool Staging::slot_free_now(size_t s) {
+    if (s >= slot_busy_.size() || !slot_busy_[s]) return true;
+    const hipError_t e = hipEventQuery(slot_ev_[s]);
+    if (e == hipSuccess) { slot_busy_[s] = 0; return true; }
+    if (e != hipErrorNotReady) (void)hipGetLastError();
+    return false;
+}
+bool Staging::slot_mark(size_t s, hipStream_t st) {
+    if (slot_ev_.size() <= s) { slot_ev_.resize(s + 1, nullptr); slot_busy_.resize(s + 1, 0); }
+    if (!slot_ev_[s] && hipEventCreateWithFlags(&slot_ev_[s], hipEventDisableTiming) != hipSuccess) { slot_ev_[s] = nullptr; return false; }
+    if (hipEventRecord(slot_ev_[s], st) != hipSuccess) return false;
+    slot_busy_[s] = 1;
+    return true;
+}
+bool Staging::drain_slots() {
+    for (size_t s = 0; s < slot_busy_.size(); ++s) if (!slot_wait(s)) return false;
+    return true;
+}
+
 void Staging::parallel_for(size_t n, const std::function<void(size_t)>& fn) {
     if (n <= 1) { if (n) fn(0); return; }
     Pool* p = pool();
@@ -199,32 +232,60 @@ hipError_t Staging::upload(const std::vector<Seg>& segs, size_t slab_bytes, uint
     if (!pin) return hipErrorOutOfMemory;
     hipStream_t c1 = stream(1), c2 = stream(2);
     if (!c1 || !c2) return hipErrorUnknown;
+    // DIRECT: the whole address space [0, slab_bytes) fits the slab — a byte's place in the slab is its offset (the callers keep
+    // the moves of one call apart by their ranges).  RING: it does not — every task (<= kPiece of the address space, one DMA)
+    // borrows the next slot of the ring, and waits for the copy that last read that slot.
+    const bool ring = slab_bytes > pin_cap_;
+    const size_t nslots = pin_cap_ / kPiece;
+    if (ring && nslots < 2) return hipErrorOutOfMemory;
+    if (!ring && !drain_slots()) return hipErrorUnknown;
     size_t span_a = SIZE_MAX, span_b = 0;
     for (const Seg& s : segs) if (s.len) { if (s.slab_off < span_a) span_a = s.slab_off; if (s.slab_off + s.len > span_b) span_b = s.slab_off + s.len; }
     // (one copy over the whole span only while the span is mostly payload: sparse segments — small payloads in large slots —
     //  take the piecewise path, which moves what the segments cover)
     if (total <= kInline && span_b - span_a <= 2 * total) {
-        size_t a = SIZE_MAX, b = 0;
-        for (const Seg& s : segs) if (s.len) { memcpy(pin + s.slab_off, s.host, s.len); if (s.slab_off < a) a = s.slab_off; if (s.slab_off + s.len > b) b = s.slab_off + s.len; }
-        TRY(hipMemcpyAsync(d_base + a, pin + a, b - a, hipMemcpyHostToDevice, c1));
-        ++counters.h2d_copies; counters.h2d_bytes += b - a;
+        size_t slot = 0;
+        if (ring) { slot = next_slot_; next_slot_ = (next_slot_ + 1) % nslots; if (!slot_wait(slot)) return hipErrorUnknown; }
+        uint8_t* const base = ring ? pin + slot * kPiece - span_a : pin;      // (a byte of the address space at offset o sits at base + o)
+        for (const Seg& s : segs) if (s.len) memcpy(base + s.slab_off, s.host, s.len);
+        TRY(hipMemcpyAsync(d_base + span_a, base + span_a, span_b - span_a, hipMemcpyHostToDevice, c1));
+        ++counters.h2d_copies; counters.h2d_bytes += span_b - span_a;
+        if (ring && !slot_mark(slot, c1)) return hipErrorUnknown;
     } else {
         std::vector<Piece> pieces; std::vector<Task> tasks;
         plan(segs, pieces, tasks);
         Pool* p = pool();
-        std::vector<std::atomic<uint8_t>> done(tasks.size());
+        const size_t n = tasks.size();
+        std::vector<std::atomic<uint8_t>> done(n);
         for (auto& d : done) d.store(0, std::memory_order_relaxed);
-        for (size_t k = 0; k < tasks.size(); ++k)
-            p->submit([&, k] {
+        std::vector<size_t> slot_of(ring ? n : 0);
+        auto submit = [&](size_t k) {
+            uint8_t* const base = ring ? pin + slot_of[k] * kPiece - tasks[k].a : pin;
+            p->submit([&, k, base] {
                 const Task& t = tasks[k];
-                for (size_t i = t.first; i < t.first + t.count; ++i) memcpy(pin + pieces[i].slab_off, pieces[i].host, pieces[i].len);
+                for (size_t i = t.first; i < t.first + t.count; ++i) memcpy(base + pieces[i].slab_off, pieces[i].host, pieces[i].len);
                 done[k].store(1, std::memory_order_release);
             });
+        };
         hipError_t err = hipSuccess;
-        for (size_t k = 0; k < tasks.size(); ++k) {
-            p->wait_until([&] { return done[k].load(std::memory_order_acquire) != 0; });
-            if (err == hipSuccess) err = hipMemcpyAsync(d_base + tasks[k].a, pin + tasks[k].a, tasks[k].b - tasks[k].a, hipMemcpyHostToDevice, (k & 1) ? c2 : c1);
-            ++counters.h2d_copies; counters.h2d_bytes += tasks[k].b - tasks[k].a;
+        size_t sub = 0, iss = 0;                       // tasks handed to the workers / tasks whose DMA is issued
+        if (!ring) for (; sub < n; ++sub) submit(sub);
+        while (iss < n) {
+            if (ring) {
+                // hand out tasks while the next slot of the ring is free (at most nslots tasks between memcpy and the end of their DMA)
+                while (sub < n && sub - iss < nslots && slot_free_now(next_slot_)) { slot_of[sub] = next_slot_; next_slot_ = (next_slot_ + 1) % nslots; submit(sub); ++sub; }
+                if (sub == iss) {                      // nothing in the workers' hands: the slot's last copy has to finish first
+                    if (!slot_wait(next_slot_)) { err = hipErrorUnknown; break; }
+                    continue;
+                }
+            }
+            p->wait_until([&] { return done[iss].load(std::memory_order_acquire) != 0; });
+            hipStream_t c = (iss & 1) ? c2 : c1;
+            uint8_t* const base = ring ? pin + slot_of[iss] * kPiece - tasks[iss].a : pin;
+            if (err == hipSuccess) err = hipMemcpyAsync(d_base + tasks[iss].a, base + tasks[iss].a, tasks[iss].b - tasks[iss].a, hipMemcpyHostToDevice, c);
+            ++counters.h2d_copies; counters.h2d_bytes += tasks[iss].b - tasks[iss].a;
+            if (ring && err == hipSuccess && !slot_mark(slot_of[iss], c)) err = hipErrorUnknown;
+            ++iss;
         }
         p->wait();
         TRY(err);
@@ -255,38 +316,67 @@ hipError_t Staging::download(const std::vector<Seg>& segs, size_t slab_bytes, co
     if (!total) { if (before) TRY(hipStreamSynchronize(before)); if (ready) TRY(hipEventSynchronize(ready)); return hipSuccess; }
     uint8_t* pin = pinned(slab_bytes);
     if (!pin) return hipErrorOutOfMemory;
+    const bool ring = slab_bytes > pin_cap_;         // (see upload)
+    const size_t nslots = pin_cap_ / kPiece;
+    if (ring && nslots < 2) return hipErrorOutOfMemory;
+    if (!ring && !drain_slots()) return hipErrorUnknown;
     size_t span_a = SIZE_MAX, span_b = 0;
     for (const Seg& s : segs) if (s.len) { if (s.slab_off < span_a) span_a = s.slab_off; if (s.slab_off + s.len > span_b) span_b = s.slab_off + s.len; }
     if (total <= kInline && span_b - span_a <= 2 * total) {
-        size_t a = SIZE_MAX, b = 0;
-        for (const Seg& s : segs) if (s.len) { if (s.slab_off < a) a = s.slab_off; if (s.slab_off + s.len > b) b = s.slab_off + s.len; }
-        TRY(hipMemcpyAsync(pin + a, d_base + a, b - a, hipMemcpyDeviceToHost, c1));
-        ++counters.d2h_copies; counters.d2h_bytes += b - a;
+        size_t slot = 0;
+        if (ring) { slot = next_slot_; next_slot_ = (next_slot_ + 1) % nslots; if (!slot_wait(slot)) return hipErrorUnknown; }
+        uint8_t* const base = ring ? pin + slot * kPiece - span_a : pin;
+        TRY(hipMemcpyAsync(base + span_a, d_base + span_a, span_b - span_a, hipMemcpyDeviceToHost, c1));
+        ++counters.d2h_copies; counters.d2h_bytes += span_b - span_a;
         TRY(hipStreamSynchronize(c1));
-        for (const Seg& s : segs) if (s.len) memcpy(s.host, pin + s.slab_off, s.len);
+        for (const Seg& s : segs) if (s.len) memcpy(s.host, base + s.slab_off, s.len);
         return hipSuccess;
     }
     std::vector<Piece> pieces; std::vector<Task> tasks;
     plan(segs, pieces, tasks);
     Pool* p = pool();
-    for (size_t k = 0; k < tasks.size(); ++k) {
-        hipEvent_t e = event(2 + k);
-        if (!e) return hipErrorUnknown;
-        hipStream_t c = (k & 1) ? c2 : c1;
-        TRY(hipMemcpyAsync(pin + tasks[k].a, d_base + tasks[k].a, tasks[k].b - tasks[k].a, hipMemcpyDeviceToHost, c));
-        ++counters.d2h_copies; counters.d2h_bytes += tasks[k].b - tasks[k].a;
-        TRY(hipEventRecord(e, c));
-    }
+    const size_t n = tasks.size();
+    std::vector<std::atomic<uint8_t>> copied(n);     // the workers have taken task k's bytes out of its slot
+    for (auto& d : copied) d.store(0, std::memory_order_relaxed);
+    std::vector<size_t> slot_of(ring ? n : 0);
     hipError_t err = hipSuccess;
-    for (size_t k = 0; k < tasks.size(); ++k) {
-        if (err == hipSuccess) err = hipEventSynchronize(events_[2 + k]);
+    size_t iss = 0, hand = 0;                         // tasks whose DMA is issued / tasks handed to the workers
+    while (hand < n && err == hipSuccess) {
+        // issue DMAs while slots are free: direct, every task has its own place; ring, task k takes the slot task k - nslots has left
+        while (iss < n && err == hipSuccess) {
+            if (ring) {
+                if (iss >= nslots && !copied[iss - nslots].load(std::memory_order_acquire)) break;
+                const size_t slot = iss < nslots ? (next_slot_ + iss) % nslots : slot_of[iss - nslots];
+                if (iss < nslots && !slot_wait(slot)) { err = hipErrorUnknown; break; }      // (an upload of an earlier call may still read it)
+                slot_of[iss] = slot;
+            }
+            hipEvent_t e = event(2 + iss);
+            if (!e) { err = hipErrorUnknown; break; }
+            hipStream_t c = (iss & 1) ? c2 : c1;
+            uint8_t* const base = ring ? pin + slot_of[iss] * kPiece - tasks[iss].a : pin;
+            err = hipMemcpyAsync(base + tasks[iss].a, d_base + tasks[iss].a, tasks[iss].b - tasks[iss].a, hipMemcpyDeviceToHost, c);
+            ++counters.d2h_copies; counters.d2h_bytes += tasks[iss].b - tasks[iss].a;
+            if (err == hipSuccess) err = hipEventRecord(e, c);
+            ++iss;
+        }
         if (err != hipSuccess) break;
-        p->submit([&, k] {
-            const Task& t = tasks[k];
-            for (size_t i = t.first; i < t.first + t.count; ++i) memcpy(pieces[i].host, pin + pieces[i].slab_off, pieces[i].len);
-        });
+        if (hand < iss) {
+            err = hipEventSynchronize(events_[2 + hand]);
+            if (err != hipSuccess) break;
+            const size_t k = hand;
+            uint8_t* const base = ring ? pin + slot_of[k] * kPiece - tasks[k].a : pin;
+            p->submit([&, k, base] {
+                const Task& t = tasks[k];
+                for (size_t i = t.first; i < t.first + t.count; ++i) memcpy(pieces[i].host, base + pieces[i].slab_off, pieces[i].len);
+                copied[k].store(1, std::memory_order_release);
+            });
+            ++hand;
+        } else {
+            p->wait_until([&] { return copied[iss - nslots].load(std::memory_order_acquire) != 0; });     // every issued task is with the workers: wait for a slot
+        }
     }
     p->wait();
+    if (ring) next_slot_ = (next_slot_ + (n < nslots ? n : nslots)) % nslots;
     return err;
 }
 

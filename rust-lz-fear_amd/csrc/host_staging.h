@@ -2,7 +2,9 @@
 //
 // The reference's frame layer streams io::Read -> Vec -> io::Write one block at a time (src/framed/compress.rs:222-263,
 // src/framed/decompress.rs:198-279).  Here a call moves all of its blocks at once, so the moves are built for PCIe:
-//   * one pinned slab (kept between calls, grown on demand) is the only memory the DMA engines touch;
+//   * one pinned slab (kept between calls, grown on demand up to 2 GiB) is the only memory the DMA engines touch; a move larger
+//     than the slab goes through it as a ring of 4 MiB slots (a slot is reused when the copy that last read it has finished), so
+//     the size of a pass is bounded by device memory, not by pinned host memory;
 //   * worker threads copy the caller's pageable buffers into / out of the slab in pieces of a few MiB while the calling
 //     thread issues one asynchronous H2D / D2H copy per finished piece — the memcpy of piece k + 1 overlaps the DMA of k;
 //   * device scratch is kept between calls as well (hipMalloc / hipFree of gigabytes cost more than the kernels).
@@ -52,6 +54,12 @@ private:
     struct Pool;
     Pool* pool();
     hipEvent_t event(size_t i);
+    // the slab as a ring of slots (host_staging.cpp): moves larger than the slab
+    bool slot_wait(size_t s);
+    bool slot_free_now(size_t s);
+    bool slot_mark(size_t s, hipStream_t st);
+    bool drain_slots();
+    std::vector<hipEvent_t> slot_ev_; std::vector<uint8_t> slot_busy_; size_t next_slot_ = 0;
     std::mutex mu_;
     uint8_t* pin_ = nullptr; size_t pin_cap_ = 0;
     uint8_t* mail_ = nullptr; size_t mail_cap_ = 0;
