@@ -162,9 +162,14 @@ void lzf_frame_release_scratch(void);
  * threads are REQUIRED; they are a throughput option).  The threads are created on first use and kept. */
 #define LZF_HOST_THREADS_NONE 0xFFFFFFFFu
 void lzf_frame_set_host_threads(uint32_t n);
-/* Device memory one pass of lzf_frame_decompress_many may use (0 = half of what is free): more frames than fit are
- * processed in several passes; a frame that does not fit alone gets status LZF_E_NO_MEMORY. */
+/* Device memory one pass of lzf_frame_decompress_many / lzf_frame_compress_many may use (0 = half of what is free): more frames
+ * than fit are processed in several passes; a frame that does not fit alone gets status LZF_E_NO_MEMORY (decompress) or is a
+ * pass of its own (compress). */
 void lzf_frame_set_memory_budget(size_t bytes);
+/* Pinned host memory the staging may hold (0 = default: 2 GiB; at least two 4 MiB slots).  A pass that moves more than this
+ * recycles the slab as a ring of 4 MiB slots — a slot is reused when the DMA that last read it has finished — so the pinned
+ * footprint of a call is bounded whatever the size of the call.  Changing it gives the current slab back. */
+void lzf_frame_set_pinned_limit(size_t bytes);
 
 /* XXH32 on the host (header / content checksums; twox-hash XxHash32 in the reference). */
 uint32_t lzf_xxh32(const uint8_t* p, size_t len, uint32_t seed);

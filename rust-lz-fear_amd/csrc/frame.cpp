@@ -456,6 +456,12 @@ void lzf_frame_set_host_threads(uint32_t n) {
     sg.set_threads(n);
 }
 
+void lzf_frame_set_pinned_limit(size_t bytes) {
+    Staging& sg = Staging::get();
+    std::lock_guard<std::mutex> g(sg.lock());
+    sg.set_pinned_limit(bytes);
+}
+
 // One pass of lzf_frame_compress_many: the frames given travel together (one pinned slab, one set of device buffers).
 static int compress_many_pass(const lzf_settings* s, uint32_t n_frames, const uint8_t* const* in, const size_t* in_len,
                               uint8_t* const* out, const size_t* out_cap, size_t* out_len, int* status);

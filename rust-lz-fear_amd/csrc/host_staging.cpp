@@ -115,6 +115,12 @@ Staging::Pool* Staging::pool() {
     if (!pool_) pool_ = new Pool(want);
     return pool_;
 }
+void Staging::set_pinned_limit(size_t bytes) {
+    if (bytes && bytes < 2 * kPiece) bytes = 2 * kPiece;
+    if (bytes == ring_max_) return;
+    ring_max_ = bytes;
+    if (pin_) { (void)drain_slots(); (void)hipHostFree(pin_); pin_ = nullptr; pin_cap_ = 0; next_slot_ = 0; (void)hipGetLastError(); }
+}
 void Staging::set_threads(unsigned n) { want_threads_ = n == 0xFFFFFFFFu ? kNoThreads : n > 64 ? 64 : n; }
 
 void Staging::release() {
@@ -135,7 +141,7 @@ void Staging::release() {
 uint8_t* Staging::pinned(size_t bytes) {
     int dev = -1; if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     if (device_ != dev) { release(); device_ = dev; }
-    if (bytes > kRingMax) bytes = kRingMax;            // (a move larger than the slab recycles it slot by slot: upload / download)
+    { const size_t lim = ring_max_ ? ring_max_ : kRingMax; if (bytes > lim) bytes = lim; }     // (a move larger than the slab recycles it slot by slot: upload / download)
     if (bytes <= pin_cap_ && pin_) return pin_;
     if (pin_) { if (!drain_slots()) return nullptr; (void)hipHostFree(pin_); pin_ = nullptr; pin_cap_ = 0; }
     // (small calls pin little: 1 MiB steps below 16 MiB, 64 MiB steps beyond)

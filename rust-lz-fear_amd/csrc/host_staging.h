@@ -36,6 +36,7 @@ public:
     hipStream_t stream(int i);                         // 0: compute, 1..2: copies in, 3: checksums, 4..5: copies out (non-blocking streams)
     void release();                                    // give everything back (lzf_host_release_scratch)
     void set_threads(unsigned n);                      // worker threads for the next calls (0 = default)
+    void set_pinned_limit(size_t bytes);               // the slab stops growing here (0 = default 2 GiB; at least two slots); gives the current slab back
     size_t pinned_capacity() const { return pin_cap_; }
 
     // ---- moves ----
@@ -60,6 +61,7 @@ private:
     bool slot_mark(size_t s, hipStream_t st);
     bool drain_slots();
     std::vector<hipEvent_t> slot_ev_; std::vector<uint8_t> slot_busy_; size_t next_slot_ = 0;
+    size_t ring_max_ = 0;                              // 0: kRingMax
     std::mutex mu_;
     uint8_t* pin_ = nullptr; size_t pin_cap_ = 0;
     uint8_t* mail_ = nullptr; size_t mail_cap_ = 0;

@@ -79,6 +79,7 @@ FRAME_EXPORTS = [
     "lzf_frame_reader_finished", "lzf_frame_reader_consumed",
     "lzf_frame_writer_new", "lzf_frame_writer_write", "lzf_frame_writer_finish", "lzf_frame_writer_sink_error", "lzf_frame_writer_free",
     "lzf_frame_get_stats", "lzf_frame_release_scratch", "lzf_frame_set_host_threads", "lzf_frame_set_memory_budget",
+    "lzf_frame_set_pinned_limit",
 ]
 
 
@@ -167,6 +168,8 @@ def lib():
         L.lzf_frame_set_host_threads.restype = None
         L.lzf_frame_set_memory_budget.argtypes = [C.c_size_t]
         L.lzf_frame_set_memory_budget.restype = None
+        L.lzf_frame_set_pinned_limit.argtypes = [C.c_size_t]
+        L.lzf_frame_set_pinned_limit.restype = None
         _lib = L
     return _lib
 

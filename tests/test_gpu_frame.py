@@ -665,6 +665,34 @@ def test_decompress_many_memory_budget_slices_and_refuses():
     assert framed.decompress_frames([big], caps=[48 << 20])[0][0] == 0                  # fits under the default budget
 
 
+def test_many_frames_through_a_pinned_ring_smaller_than_the_call():
+    """host_staging.cpp: a pass that moves more than the pinned slab may hold goes through it as a ring of 4 MiB slots (a slot is
+    reused when the DMA that last read it has finished).  With the slab limited to 12 MiB — three slots — 24 frames (72 MiB in,
+    every payload and every decoded byte out) make the ring go round many times in both directions: frames == the oracle's,
+    round trip exact, linked frames and dictionary frames (their own layouts of the slab) included, small frames (the inline
+    path borrows a slot too) in between, and the pinned footprint stays at the limit."""
+    from rust_lz_fear_amd import ffi
+    datas = [synth.silesia_mix((7 * k) << 20, ((7 * k) << 20) + (3 << 20) + 4099 * k).tobytes() for k in range(20)] + [b"", b"abc" * 50, synth.silesia_mix(0, 70_000).tobytes(), b"x" * 300_000]
+    dic = synth.silesia_mix(1 << 20, (1 << 20) + 20_000).tobytes()
+    ffi.lib().lzf_frame_release_scratch()
+    ffi.lib().lzf_frame_set_pinned_limit(12 << 20)
+    try:
+        for kw in (dict(block_size=256 << 10), dict(block_size=64 << 10, independent_blocks=False), dict(block_size=1 << 20, block_checksums=True, dictionary=dic)):
+            so = o.make_settings(**{k: v for k, v in kw.items() if k != "dictionary"}, **({"dictionary": dic, "dictionary_id": 0} if "dictionary" in kw else {}))
+            want = [o.frame_compress(d, so)[1] for d in datas]
+            cs = framed.CompressionSettings().block_size(kw["block_size"]).independent_blocks(kw.get("independent_blocks", True)).block_checksums(kw.get("block_checksums", False))
+            if "dictionary" in kw:
+                cs = cs.dictionary(0, dic)
+            got = cs.compress_many(datas)
+            assert got == want, kw
+            back = framed.decompress_frames(got, dictionary=kw.get("dictionary", b""), caps=[len(d) + 64 for d in datas])
+            assert back == [(0, d) for d in datas], kw
+            assert 0 < ffi.frame_stats()["pinned_bytes"] <= 12 << 20
+    finally:
+        ffi.lib().lzf_frame_set_pinned_limit(0)
+        ffi.lib().lzf_frame_release_scratch()
+
+
 def test_c_abi_block_reader_is_decode_block():
     """lzf_frame_reader_* == LZ4FrameReader::new + decode_block, block by block: same blocks, same error kind at the same
     block, same bytes consumed, dictionary and carried window included."""
