@@ -380,7 +380,8 @@ int seg_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, 
 // 13.0 of its 27.8 wave-instructions per sequence, the hop parse 3.8 — then the pair kernel over whatever that left (errors,
 // sizes outside the map's window, a chain that did not verify).
 constexpr auto k_fed32 = lzf::lzf_decompress_fed_kernel<4096, 32, 352>;
-constexpr uint32_t kFedMinInDefault = 1024u;                         // smaller inputs are left to the pair kernel
+constexpr uint32_t kFedMinInDefault = 65536u;                        // smaller inputs are left to the pair kernel: per job the feed costs a census of pieces, a chunk's parse and a ring
+                                                                     // re-fill — 16 384 jobs of ~32 KiB ran at 380 GiB/s through it and at 484 through the pair kernel (bench config5, u16_raw)
 inline uint32_t fed_min_in() {
 #ifdef LZF_ANALYSIS      // LZF_FED_MIN_IN: the smallest input the bitmap-fed kernel takes (the variant parity test opens it to every input)
     static const long v = [] { const char* e = getenv("LZF_FED_MIN_IN"); return e ? atol(e) : -1L; }();
@@ -426,7 +427,7 @@ FedGeometry fed_geometry(hipStream_t st) {
 }
 int fed_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n, const uint32_t* perm, hipStream_t st, bool* used, uint64_t max_in_hint) {
     *used = false;
-    if (n > kFedMaxJobs || max_in_hint < fed_min_in()) return LZF_OK;
+    if (n > kFedMaxJobs || max_in_hint <= fed_min_in()) return LZF_OK;   // (a caller that bounds its inputs — lzf_decompress_batch_sized, the frame layer — spares small-block batches the empty launches)
     SegScratch s;
     lzf::seg_ctx& c = s.ctx;
     c = lzf::seg_ctx{};
