@@ -569,7 +569,8 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
             LAUNCH(k_compact, dim3(n_jobs), dim3(64), pad, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, fresh_only ? 1u : 0u);
         }
 #endif
-        if (!fresh_only) LAUNCH(k_general_u32, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, use_compact, (const uint32_t*)perm);
+        // (behind the team kernel the general kernel skips what that one takes — compact jobs and caller-owned U32 tables — unless a job was handed back)
+        if (!fresh_only) LAUNCH(k_general_u32, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, use_team ? 2u : use_compact, (const uint32_t*)perm);
     }
     if (table_kinds & LZF_KINDS_U16)
         LAUNCH(k_general_u16, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, 0u, (const uint32_t*)perm);

@@ -60,7 +60,8 @@ __global__ __launch_bounds__(64) void lzf_compress_wave_kernel(
     const lzf_compress_job job = jobs[jid];
     const long long t_start = clock64();
     if (job.table_kind != (uint32_t)KIND) return;   // handled by the other instantiation
-    if (skip_compact && compress_job_is_compact(job)) return;   // handled by lzf_compress_compact_kernel
+    if (skip_compact == 1u && compress_job_is_compact(job)) return;   // handled by lzf_compress_compact_kernel
+    if (skip_compact == 2u && compress_job_is_team(job) && results[jid].status != kTeamRetry) return;   // handled by lzf_compress_team_kernel (unless it hands the job back)
 
     cgu8* __restrict__ in = as_global(job.input);
     int status = LZF_OK;

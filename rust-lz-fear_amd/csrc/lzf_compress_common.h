@@ -45,4 +45,23 @@ LZF_SIMT_FN bool compress_job_is_compact(const lzf_compress_job& job) {
     return ((const LZF_GLOBAL lzf_u32_table*)job.table)->offset == 0ull;
 }
 
+// What lzf_compress_team_kernel (lz4_compress_team.inc: the latency class) takes when another kernel stands behind it: every
+// compact job, and — round 6 — U32 jobs with a caller-owned table at any `offset` (mod.rs:30,:65-74): linked-block streams
+// (framed/compress.rs:271-275), read at start, written back at the end.  The kernel keeps positions in its LDS table and
+// applies the offset on the way in and out, which is exact as long as position + offset fits the slot (:67: else the reference
+// panics — those jobs stay with the general kernel, which says LZF_CONTRACT) and position 0 is never inserted behind an
+// offset (cursor > 0: see the write-back in lz4_compress_team.inc).
+LZF_SIMT_FN bool compress_job_is_team(const lzf_compress_job& job) {
+    if (job.table_kind != LZF_TABLE_U32 || job.input_len >= kMaxLen || job.cursor > job.input_len) return false;
+    if (!job.table) return true;
+    const uint64_t off = ((const LZF_GLOBAL lzf_u32_table*)job.table)->offset;
+    if (off == 0ull) return true;
+    return job.cursor > 0u && off + job.input_len <= 0xFFFFFFFFull;
+}
+// Internal status of a team job whose writer refused while its table is the caller's: the searcher runs ahead of the emitter,
+// so the table in LDS is past the refused sequence — nothing is written back, and the general kernel launched behind the
+// team kernel does the job again from the caller's table (it leaves the table as the reference does, mod.rs:150-163 with
+// framed/compress.rs:294-314).  Never seen by a caller.
+constexpr int kTeamRetry = -30000;
+
 }  // namespace lzf

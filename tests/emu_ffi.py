@@ -46,7 +46,7 @@ def team_lib():
     return _team
 
 
-def compress_batch(inputs, cursors=None, caps=None, tables=None, perm=None, pad=64, kernel="team"):
+def compress_batch(inputs, cursors=None, caps=None, tables=None, perm=None, pad=64, kernel="team", writable=False, alone=1):
     """Runs the emulated team kernel over a batch.  inputs: list of bytes.  Returns [(status, bytes)], lock-step points per wave sum."""
     n = len(inputs)
     jobs = (CompressJob * n)()
@@ -69,14 +69,14 @@ def compress_batch(inputs, cursors=None, caps=None, tables=None, perm=None, pad=
         jobs[i].out_cap = cap
         if tables is not None and tables[i] is not None:
             jobs[i].table = C.addressof(tables[i])
-            jobs[i].flags = 1
+            jobs[i].flags = 0 if writable else 1          # LZF_CJOB_TABLE_READONLY unless the table is the caller's to keep
         jobs[i].table_kind = 0
     permarr = None
     if perm is not None:
         permarr = (C.c_uint32 * n)(*perm)
     ns = C.c_uint64(0)
     assert kernel == "team"
-    rc = team_lib().lzf_emu_compress_team(jobs, res, n, permarr, 1, C.byref(ns))
+    rc = team_lib().lzf_emu_compress_team(jobs, res, n, permarr, alone, C.byref(ns))
     assert rc == 0, rc
     result = []
     for i in range(n):

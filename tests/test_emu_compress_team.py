@@ -163,3 +163,48 @@ def test_ring_skips_and_far_candidates():
     inputs = [data, data[:300000], data]
     cursors = [250000, 131072, 66000]
     expect(inputs, run(inputs, cursors=cursors), cursors=cursors)
+
+
+def test_caller_owned_tables_with_offsets_linked_blocks():
+    """Round 6: with the general kernel behind it (alone = 0) the team kernel takes caller-owned U32 tables at any EncoderTable::offset
+    (mod.rs:30,:65-74) — the linked-blocks loop of framed/compress.rs:222-276: in_buffer = window ++ block, compress2 from the window's
+    end, table.offset(what the window forgets).  After every block the output AND the table's 4096 slots + offset equal the oracle's;
+    a refused block (cap = N on noise) is handed back (internal status, nothing written back: the general kernel's job on the device)."""
+    WINDOW = 65536
+    rng = random.Random(11)
+    streams = [synth.silesia_mix(3 << 20, (3 << 20) + 400_000).tobytes(),
+               synth.repeat256(150_000).tobytes() + synth.gen_random(5, 130_000).tobytes() + synth.silesia_mix(0, 120_000).tobytes(),
+               b"".join(bytes([rng.randrange(4)]) * rng.randrange(1, 40) for _ in range(9000))]
+    refused = compared_behind_offset = 0
+    for data, bs in zip(streams, (65536, 40_000, 65536)):
+        dic = data[:5000]
+        t_emu, t_or = o.new_table(), o.new_table()
+        # (the template of framed/compress.rs:202-211 is not the subject here: both sides start from the same seeded table)
+        buf = dic
+        o.compress2(dic + b"\0" * 16, cursor=len(dic) + 16, table=t_or); C.memmove(C.addressof(t_emu), C.addressof(t_or), C.sizeof(t_or))
+        pos = len(dic)
+        k = 0
+        while pos < len(data):
+            block = data[pos:pos + bs]; pos += len(block)
+            inb = buf + block
+            cap = len(block) if k % 3 else None               # framed/compress.rs:242 (cap = N) on most blocks
+            erc, eout = o.compress2(inb, cursor=len(buf), table=t_or, cap=cap)
+            before = bytes(t_emu)
+            (rc, out), = emu_ffi.compress_batch([inb], cursors=[len(buf)], caps=[cap], tables=[t_emu], writable=True, alone=0)[0]
+            if erc == 5:                                       # LZF_OUTPUT_FULL: handed back, the caller's table untouched
+                assert rc == -30000 and bytes(t_emu) == before, (k, rc)
+                refused += 1
+                C.memmove(C.addressof(t_emu), C.addressof(t_or), C.sizeof(t_or))      # (what the general kernel leaves: tests/test_gpu_parity.py)
+            else:
+                assert (rc, out) == (erc, eout), (k, rc, erc, len(out), len(eout))
+                assert bytes(t_emu) == bytes(t_or), (k, "table after the block")
+                compared_behind_offset += t_or.offset > 0
+            buf = inb
+            if len(buf) > WINDOW:                              # framed/compress.rs:271-275
+                forget = len(buf) - WINDOW
+                for t in (t_emu, t_or):
+                    t.offset += forget
+                buf = buf[forget:]
+            k += 1
+        assert t_or.offset > 0 and k >= 3
+    assert refused >= 1 and compared_behind_offset >= 6, (refused, compared_behind_offset)

@@ -545,6 +545,48 @@ def test_compress_with_prefix_and_table_carry_linked_blocks():
             buf = buf[forget:]
 
 
+def test_linked_streams_of_one_call_take_the_team_class_tables_exact():
+    """Round 6 (review item 7): a linked-blocks call of no more streams than compute units — block k of 200 streams in launch k — runs in
+    the compressor's latency class, lzf_compress_team_kernel, with the caller-owned tables carried (offset applied on the way in and out of
+    LDS); the general kernel behind it takes what the team kernel hands back (a refused block: cap = N on noise) and U16 / contract jobs.
+    Output bytes, statuses and the tables' bytes after EVERY block == the oracle's linked loop (framed/compress.rs:221-276)."""
+    S, bs, nblk = 200, 65536, 4
+    rng = np.random.default_rng(12)
+    datas = []
+    for k in range(S):
+        a = int(rng.integers(0, 180 << 20))
+        d = bytearray(synth.silesia_mix(a, a + bs * nblk - 1000 * (k % 7)).tobytes())
+        if k % 9 == 4:
+            d[bs + 100:2 * bs + 5000] = synth.gen_random(k, bs + 4900).tobytes()      # blocks 1 (and part of 2) of these streams are noise: refused at cap = N
+        datas.append(bytes(d))
+    tg = [ffi.U32Table() for _ in range(S)]
+    to = [o.new_table() for _ in range(S)]
+    bufs = [b""] * S
+    refused = 0
+    for b in range(nblk):
+        items, exp = [], []
+        for k in range(S):
+            blk = datas[k][b * bs:(b + 1) * bs]
+            inp = bufs[k] + blk
+            exp.append(o.compress2(inp, cursor=len(bufs[k]), table=to[k], cap=len(blk)))
+            items.append(dict(input=inp, cursor=len(bufs[k]), table=tg[k], out_cap=len(blk)))
+        res = gpu_compress(items)
+        assert ffi.lib().lzf_last_compress_launch().decode() == "lzf_compress_team_kernel + lzf_compress_wave_kernel"
+        for k in range(S):
+            assert res[k][0] == exp[k][0], (b, k, res[k][0], exp[k][0])
+            if exp[k][0] == 0:
+                assert res[k][1] == exp[k][1], (b, k)
+            else:
+                refused += 1
+            assert bytes(tg[k]) == bytes(to[k]), (b, k, "table after the block")
+            bufs[k] = items[k]["input"]
+            if len(bufs[k]) > 65536:
+                forget = len(bufs[k]) - 65536
+                tg[k].offset += forget; to[k].offset += forget
+                bufs[k] = bufs[k][forget:]
+    assert refused >= 20 and all(t.offset > 0 for t in to)
+
+
 def test_compress_dictionary_template_table():
     """Template table seeded from a dictionary (framed/compress.rs:202-214), read-only clone per block."""
     dic = synth.gen_text_zipf(3, 70000).tobytes()
