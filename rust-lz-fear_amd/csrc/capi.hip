@@ -425,11 +425,16 @@ FedGeometry fed_geometry(hipStream_t st) {
     by_dev[dev] = answer;
     return answer;
 }
-int fed_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n, const uint32_t* perm, hipStream_t st, bool* used, uint64_t max_in_hint) {
-    *used = false;
-    if (n > kFedMaxJobs || max_in_hint <= fed_min_in()) return LZF_OK;   // (a caller that bounds its inputs — lzf_decompress_batch_sized, the frame layer — spares small-block batches the empty launches)
-    SegScratch s;
-    lzf::seg_ctx& c = s.ctx;
+// A call (or one half of it) in two steps: FRONT = scratch + plan, parse, seam (the bit maps); BACK = the copy stage fed from them and
+// the pair kernel over what is left, then the scratch goes back.  The two steps may run on different streams (the caller orders them).
+struct FedCall {
+    SegScratch s; const lzf_decompress_job* jobs = nullptr; lzf_job_result* res = nullptr; uint32_t n = 0; const uint32_t* perm = nullptr;
+    size_t o_tick = 0, o_fst = 0; bool live = false;
+};
+// false: the pair kernel takes these jobs (no room for the bit maps)
+int fed_front(FedCall& f, const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n, const uint32_t* perm, hipStream_t st, uint64_t max_in_hint) {
+    f.jobs = d_jobs; f.res = d_results; f.n = n; f.perm = perm; f.live = false;
+    lzf::seg_ctx& c = f.s.ctx;
     c = lzf::seg_ctx{};
     c.jobs = d_jobs; c.results = d_results; c.n_jobs = n;
     const uint32_t max_in = max_in_hint < kSegMaxIn ? (uint32_t)(max_in_hint < lzf::kSegChunk ? lzf::kSegChunk : max_in_hint) : kSegMaxIn;
@@ -445,45 +450,64 @@ int fed_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, 
     const size_t o_x = take(sizeof(uint32_t) * (size_t)n * c.maxch);
     const size_t o_vf = take(sizeof(uint32_t) * (size_t)n * c.maxch);
     const size_t o_bits = take(sizeof(uint32_t) * (size_t)n * c.maxch * lzf::kSegChunkWords);
-    const size_t o_tick = take(sizeof(uint32_t) * 32u * lzf::kFedTicketStride);
-    const size_t o_fst = take(sizeof(lzf::fed_state) * (size_t)n);
+    f.o_tick = take(sizeof(uint32_t) * 32u * lzf::kFedTicketStride);
+    f.o_fst = take(sizeof(lzf::fed_state) * (size_t)n);
     if (off > kFedMaxScratch) return LZF_OK;                         // (the pair kernel takes the call)
-    if (hipMallocAsync(&s.base, off, st) != hipSuccess) { (void)hipGetLastError(); return LZF_OK; }
-    uint8_t* b = static_cast<uint8_t*>(s.base);
+    if (hipMallocAsync(&f.s.base, off, st) != hipSuccess) { (void)hipGetLastError(); f.s.base = nullptr; return LZF_OK; }
+    uint8_t* b = static_cast<uint8_t*>(f.s.base);
     c.st = reinterpret_cast<lzf::seg_job*>(b + o_st);
     c.rec_top = reinterpret_cast<unsigned long long*>(b + o_top);
     c.xexit = reinterpret_cast<uint32_t*>(b + o_x);
     c.vfrom = reinterpret_cast<uint32_t*>(b + o_vf);
     c.bits = reinterpret_cast<uint32_t*>(b + o_bits);
-    *used = true;
+    f.live = true;
+    const int rc = seg_launch(c, 3u, st);                            // plan, parse, seam
+    if (rc != LZF_OK) { (void)hipFreeAsync(f.s.base, st); f.s.base = nullptr; f.live = false; g_last_error = "bitmap-fed decompress: launch failed"; }
+    return rc;
+}
+// slots_per_cu = 0: as many slots as the device holds (fed_geometry)
+int fed_back(FedCall& f, hipStream_t st, uint32_t slots_per_cu) {
+    if (!f.live) return LZF_OK;
+    lzf::seg_ctx& c = f.s.ctx;
+    const uint32_t n = f.n;
+    uint8_t* b = static_cast<uint8_t*>(f.s.base);
     // The kernel runs as one wavefront per SLOT — as many as the device holds at once — and the slots share the jobs out in pieces
     // (lz4_decompress_fed.hip): a call with more jobs than slots cuts every job into 16 (measured at 2.2 jobs per slot: 107.4 ms whole, 97.3 / 97.2 / 97.8 / 99.0 / 101.7 ms with
     // 8 / 16 / 32 / 64 / 128 pieces), a smaller one leaves them whole.
     const FedGeometry fg = fed_geometry(st);
     uint32_t slots = fg.slots;
+    if (slots_per_cu && slots_per_cu * cu_count() < slots) slots = slots_per_cu * cu_count();
     uint32_t pieces = n > slots && fg.xcc_mask ? 16u : 1u;
     uint32_t pad = 0;
 #ifdef LZF_ANALYSIS      // LZF_FED_PIECES = pieces per job (A/B), LZF_FED_SLOTS = slots per CU, LZF_FED_PAD_LDS = bytes of unused LDS per wavefront (residency experiment)
     { static const long e = [] { const char* v = getenv("LZF_FED_PIECES"); return v ? atol(v) : 0L; }(); if (e >= 1 && e <= 4096) pieces = (uint32_t)e; }
-    { static const long e = [] { const char* v = getenv("LZF_FED_SLOTS"); return v ? atol(v) : 0L; }(); if (e > 0) slots = (uint32_t)e * cu_count(); }
+    { static const long e = [] { const char* v = getenv("LZF_FED_SLOTS"); return v ? atol(v) : 0L; }(); if (e > 0 && !slots_per_cu) slots = (uint32_t)e * cu_count(); }
     { static const uint32_t e = [] { const char* v = getenv("LZF_FED_PAD_LDS"); return v ? (uint32_t)atol(v) : 0u; }(); pad = e; }
 #endif
     if ((uint64_t)n * pieces > 0xFFFFFFF0ull) pieces = 1u;
-    int rc = seg_launch(c, 3u, st);                                  // plan, parse, seam
+    if (!fg.xcc_mask) pieces = 1u;
+    int rc = LZF_OK;
+    lzf::fed_args a{f.jobs, f.res, c.st, c.bits, c.vfrom, f.perm, reinterpret_cast<lzf::fed_state*>(b + f.o_fst), reinterpret_cast<uint32_t*>(b + f.o_tick), fg.xcc_mask ? fg.xcc_mask : 1u, n, c.maxch, pieces, nullptr};
+    hipLaunchKernelGGL(lzf::lzf_fed_reset_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_fed32, dim3(slots < n ? slots : n), dim3(64), pad, st, a);
+    if (hipGetLastError() != hipSuccess) rc = LZF_E_HIP;
     if (rc == LZF_OK) {
-        if (!fg.xcc_mask) pieces = 1u;
-        lzf::fed_args a{d_jobs, d_results, c.st, c.bits, c.vfrom, perm, reinterpret_cast<lzf::fed_state*>(b + o_fst), reinterpret_cast<uint32_t*>(b + o_tick), fg.xcc_mask ? fg.xcc_mask : 1u, n, c.maxch, pieces, nullptr};
-        hipLaunchKernelGGL(lzf::lzf_fed_reset_kernel, dim3((n + 255u) / 256u), dim3(256), 0, st, a);
-        hipLaunchKernelGGL(k_fed32, dim3(slots < n ? slots : n), dim3(64), pad, st, a);
+        hipLaunchKernelGGL(k_paired24, dim3(n), dim3(128), 0, st, f.jobs, f.res, n, f.perm, (const lzf::seg_job*)c.st);
         if (hipGetLastError() != hipSuccess) rc = LZF_E_HIP;
     }
-    if (rc == LZF_OK) {
-        hipLaunchKernelGGL(k_paired24, dim3(n), dim3(128), 0, st, d_jobs, d_results, n, perm, (const lzf::seg_job*)c.st);
-        if (hipGetLastError() != hipSuccess) rc = LZF_E_HIP;
-    }
-    if (hipFreeAsync(s.base, st) != hipSuccess && rc == LZF_OK) rc = LZF_E_HIP;
+    if (hipFreeAsync(f.s.base, st) != hipSuccess && rc == LZF_OK) rc = LZF_E_HIP;
+    f.s.base = nullptr; f.live = false;
     if (rc != LZF_OK) g_last_error = "bitmap-fed decompress: launch failed";
     return rc;
+}
+int fed_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n, const uint32_t* perm, hipStream_t st, bool* used, uint64_t max_in_hint) {
+    *used = false;
+    if (n > kFedMaxJobs || max_in_hint <= fed_min_in()) return LZF_OK;   // (a caller that bounds its inputs — lzf_decompress_batch_sized, the frame layer — spares small-block batches the empty launches)
+    FedCall f;
+    int rc = fed_front(f, d_jobs, d_results, n, perm, st, max_in_hint);
+    if (rc != LZF_OK || !f.live) return rc;
+    *used = true;
+    return fed_back(f, st, 0u);
 }
 
 #ifdef LZF_ANALYSIS
