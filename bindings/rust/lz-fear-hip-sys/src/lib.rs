@@ -121,6 +121,7 @@ extern "C" {
     pub fn lzf_frame_release_scratch();
     pub fn lzf_frame_set_host_threads(n: u32);
     pub fn lzf_frame_set_memory_budget(bytes: usize);
+    pub fn lzf_frame_set_pinned_limit(bytes: usize);
 }
 
 // lzfear_dist.h (liblzfear_dist.so; links librccl): the one exchange of the block-sharded frame — what a multi-GPU `src/framed` calls behind
