@@ -28,6 +28,7 @@ import sys
 R = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
 TAG = next((a for a in sys.argv[1:] if not a.startswith("-")), "r06")
 QUICK = "--quick" in sys.argv
+FULL = "--full-traffic" in sys.argv          # also try the FETCH / WRITE passes at the benchmark's own 240 copies (earlier rounds: did not finish)
 O = os.path.join(R, "gpurun_out", TAG)
 os.makedirs(O, exist_ok=True)
 ENV = dict(os.environ, TMPDIR="/tmp")
@@ -59,14 +60,14 @@ def short(k):
     return k.split("(")[0]
 
 
-def pmc_pass(size, name, counters):
+def pmc_pass(size, name, counters, timeout=600):
     """One rocprofv3 --pmc pass of the bench at `size` copies.  -> ({kernel: {counter: sum}}, {kernel: dispatches}, the run's line)"""
     d = os.path.join(O, f"pmc_{size}_{name}")
     log = d + ".log"
     subprocess.run(["rm", "-rf", d])
     cmd = ["rocprofv3", "--kernel-trace", "--pmc", *counters, "--output-format", "csv", "-d", d, "--", "python", "bench.py", "--copies", str(size), "--distinct", "1",
            "--steps", "1", "--warmup", "0", "--no-verify", "--no-sweep", *COMMON]
-    rc = sh(cmd, log, 600)
+    rc = sh(cmd, log, timeout)
     for db in glob.glob(os.path.join(d, "*", "*.db")):
         os.remove(db)
     fs = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
@@ -151,6 +152,24 @@ def main():
                 issue["compress"] = {"kernel_as_profiled": short(k), "dispatches": passes["insts"][1].get(k, 0), "per_dispatch": c, "sequences": seqs,
                                      "per_sequence": {m: round(v / seqs, 2) for m, v in c.items()},
                                      "wave_instructions_per_sequence": round(sum(c.get(m, 0.0) for m in SQ[:5]) / seqs, 2)}
+    if FULL and "decompress" in traffic:
+        # the headline call at its own size: only the two traffic passes (each runs the 240-copy bench once under the counters)
+        fa, n1, line = pmc_pass(240, "FETCH_SIZE", ["FETCH_SIZE"], timeout=1500)
+        wa, n2, line2 = pmc_pass(240, "WRITE_SIZE", ["WRITE_SIZE"], timeout=1500)
+        line = line or line2
+        ks = sorted(k for k in set(fa) | set(wa) if is_decompress_kernel(k))
+        if line and ks and all(k in fa and k in wa for k in ks if "fed_kernel" in k or "parse" in k):
+            per_kernel = {short(k): {"dispatches": n1.get(k, 0), "FETCH_SIZE_KB": fa[k].get("FETCH_SIZE", 0.0), "WRITE_SIZE_KB": wa[k].get("WRITE_SIZE", 0.0)} for k in ks}
+            traffic["decompress_48"] = traffic["decompress"]
+            traffic["decompress"] = {"kernel": line["roofline"]["kernel"], "jobs": line["kernel_only"]["blocks_per_gpu"], "copies": 240, "calls": 1,
+                                     "FETCH_SIZE_KB": sum(v["FETCH_SIZE_KB"] for v in per_kernel.values()), "WRITE_SIZE_KB": sum(v["WRITE_SIZE_KB"] for v in per_kernel.values()),
+                                     "per_kernel": per_kernel}
+            ck = [k for k in fa if "lzf_compress_compact_kernel<false>" in k]
+            if ck and ck[0] in wa:
+                k = ck[0]
+                traffic["compress_48"] = traffic.get("compress")
+                traffic["compress"] = {"kernel": line["compress"]["roofline"]["kernel"], "kernel_as_profiled": short(k), "jobs": line["config"]["blocks_per_gpu"], "copies": 240,
+                                       "calls": max(1, n1.get(k, 1)), "FETCH_SIZE_KB": fa[k]["FETCH_SIZE"] / max(1, n1.get(k, 1)), "WRITE_SIZE_KB": wa[k]["WRITE_SIZE"] / max(1, n2.get(k, 1))}
     json.dump(traffic, open(os.path.join(O, "hbm_traffic.json"), "w"), indent=1)
     json.dump(issue, open(os.path.join(O, "issue_counters.json"), "w"), indent=1)
     for key in ("decompress", "tile20", "compress"):
