@@ -584,7 +584,11 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
 #ifdef LZF_DBG_DRY_MAIN      // analysis: results[].reserved = probe batches + sequences of the whole job (no output)
         if (use_compact) LAUNCH(k_compact_dry, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, 0u);
 #else
-        if (use_team) LAUNCH(lzf::lzf_compress_team_kernel, dim3(n_jobs), dim3(192), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, fresh_only ? 1u : 0u);
+        if (use_team) {
+            LAUNCH(lzf::lzf_compress_team_kernel, dim3(n_jobs), dim3(192), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm, fresh_only ? 1u : 0u);
+            // caller-owned tables (linked streams): the same team, compiled with the table carry; it leaves the compact jobs to the kernel above
+            if (!fresh_only) LAUNCH(lzf::lzf_compress_team_carry_kernel, dim3(n_jobs), dim3(192), 0, st, d_jobs, d_results, n_jobs, (const uint32_t*)perm);
+        }
         else if (use_compact) {
             uint32_t pad = 0;
 #ifdef LZF_ANALYSIS      // LZF_COMPACT_PAD_LDS = bytes of unused LDS per wavefront: fewer resident waves per CU (the residency experiment)
@@ -600,7 +604,7 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
         LAUNCH(k_general_u16, dim3(n_jobs), dim3(64), 0, st, d_jobs, d_results, n_jobs, 0u, (const uint32_t*)perm);
     g_last_compress = !(table_kinds & LZF_KINDS_U32) ? "lzf_compress_wave_kernel<U16>"
                     : !use_compact ? "lzf_compress_wave_kernel (analysis: general)"
-                    : use_team ? (fresh_only ? "lzf_compress_team_kernel" : "lzf_compress_team_kernel + lzf_compress_wave_kernel")
+                    : use_team ? (fresh_only ? "lzf_compress_team_kernel" : "lzf_compress_team_kernel + lzf_compress_team_carry_kernel + lzf_compress_wave_kernel")
                                : (fresh_only ? "lzf_compress_compact_kernel" : "lzf_compress_compact_kernel + lzf_compress_wave_kernel");
     HIP_TRY(scratch_owner.release());
     return LZF_OK;

@@ -177,6 +177,7 @@ extern template __global__ void lzf_compress_compact_kernel<true>(const lzf_comp
 // the latency class (lz4_compress_team.hip / .inc; round 5): one block per CU, searcher / emitter / feeder wavefronts, input ring and table in LDS
 __global__ void lzf_compress_team_kernel(const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs,
                                          const uint32_t* __restrict__ perm, uint32_t alone);
+__global__ void lzf_compress_team_carry_kernel(const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results, uint32_t n_jobs, const uint32_t* __restrict__ perm);
 // job ordering (aux_kernels.hip): cost probes of the compress jobs and the launch order derived from them
 __global__ void lzf_cost_probe_jobs_kernel(const lzf_compress_job* __restrict__ jobs, lzf_compress_job* __restrict__ probes, uint32_t n,
                                            uint32_t piece, uint32_t parts);

@@ -18,7 +18,17 @@ __global__ __launch_bounds__(192) void lzf_compress_team_kernel(const lzf_compre
     if ((lds_addr(lds) & 0x3FFFu) != 0u) __builtin_trap();
     const SimtGpu b{lds, lds_addr(lds)};
     const team::Args a{jobs, results, n_jobs, perm, alone};
-    team::compress_team(b, a, blockIdx.x);
+    team::compress_team<SimtGpu, false>(b, a, blockIdx.x);
+}
+
+// the jobs the kernel above leaves to lzf_compress_wave_kernel but a team can do: caller-owned U32 tables at any offset (linked streams)
+__global__ __launch_bounds__(192) void lzf_compress_team_carry_kernel(const lzf_compress_job* __restrict__ jobs, lzf_job_result* __restrict__ results,
+                                                                      uint32_t n_jobs, const uint32_t* __restrict__ perm) {
+    __shared__ __attribute__((aligned(16384))) uint32_t lds[team::kLdsWords];
+    if ((lds_addr(lds) & 0x3FFFu) != 0u) __builtin_trap();
+    const SimtGpu b{lds, lds_addr(lds)};
+    const team::Args a{jobs, results, n_jobs, perm, 0u};
+    team::compress_team<SimtGpu, true>(b, a, blockIdx.x);
 }
 
 }  // namespace lzf

@@ -52,7 +52,11 @@ void lane_entry() {
     EmuWave* w = emu_current();
     const uint32_t my = w->cur;
     SimtEmu b{w, my};
-    team::compress_team(b, *g_args, g_launch_index);
+    // (alone: the round-5 kernel, compact jobs only; with the general kernel behind it the carry kernel takes the caller-owned tables —
+    //  on the device both are launched, each leaving the other's jobs alone: here the one that owns the job runs)
+    const lzf_compress_job& j = g_args->jobs[g_args->perm ? g_args->perm[g_launch_index] : g_launch_index];
+    if (g_args->alone || compress_job_is_compact(j)) team::compress_team<SimtEmu, false>(b, *g_args, g_launch_index);
+    else team::compress_team<SimtEmu, true>(b, *g_args, g_launch_index);
     w->finished[my] = true;
     ++g_lanes_finished;
     // a finished lane keeps handing the CPU on (the other waves are still running) until every lane of the workgroup is done
