@@ -107,116 +107,6 @@ __device__ __forceinline__ void put_small_glb(uint32_t dst, cgu8* g, uint32_t n)
 // the forms below issue the reads of ALL classes (EXEC narrowed per class, no wait in between), wait once, then issue all
 // writes.  `who` = the lanes that take part (a subset of EXEC, uniform value); every lane of the wave executes the call.
 // ---------------------------------------------------------------------------------------------------------------------
-// Non-overlapping match of n = 4..64 bytes, ring -> ring, neither range wrapping: 4..7 two 4-byte pieces; 8..32 four two-ended
-// 8-byte pieces (duplicates below 17 bytes); beyond 32 the first 32 bytes here and the last 32 by put_tail_lds (caller).
-__device__ __forceinline__ void put_match_lds_1rt(uint32_t d, uint32_t s, uint32_t n, unsigned long long who) {
-    uint32_t a1, a2, a3, dl, w0, w1; uint64_t v0, v1, v2, v3; unsigned long long sv, mA, mB;
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_and_b64 exec, exec, %[who]\n\t"
-        "v_sub_u32 %[dl], %[d], %[s]\n\t"
-        "v_cmp_gt_u32 vcc, 8, %[n]\n\t"                       /* n < 8 */
-        "s_and_b64 %[mB], exec, vcc\n\t"
-        "s_andn2_b64 %[mA], exec, vcc\n\t"
-        "s_mov_b64 exec, %[mB]\n\t"
-        "v_add3_u32 %[a3], %[s], %[n], -4\n\t"
-        "ds_read_b32 %[w0], %[s]\n\t"
-        "ds_read_b32 %[w1], %[a3]\n\t"
-        "s_mov_b64 exec, %[mA]\n\t"
-        "v_cmp_lt_u32 vcc, 16, %[n]\n\t"                      /* more than two pieces */
-        "v_cndmask_b32_e64 %[a1], 0, 8, vcc\n\t"
-        "v_add_u32 %[a1], %[a1], %[s]\n\t"
-        "v_min_u32 %[a2], 32, %[n]\n\t"
-        "v_add3_u32 %[a3], %[s], %[a2], -8\n\t"               /* s + min(n, 32) - 8 */
-        "v_add_u32 %[a2], -8, %[a3]\n\t"
-        "v_cndmask_b32 %[a2], %[s], %[a2], vcc\n\t"
-        "ds_read_b64 %[v0], %[s]\n\t"
-        "ds_read_b64 %[v1], %[a1]\n\t"
-        "ds_read_b64 %[v2], %[a2]\n\t"
-        "ds_read_b64 %[v3], %[a3]\n\t"
-        "v_add_u32 %[a1], %[a1], %[dl]\n\t"
-        "v_add_u32 %[a2], %[a2], %[dl]\n\t"
-        "v_add_u32 %[a3], %[a3], %[dl]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "ds_write_b64 %[d], %[v0]\n\t"
-        "ds_write_b64 %[a1], %[v1]\n\t"
-        "ds_write_b64 %[a2], %[v2]\n\t"
-        "ds_write_b64 %[a3], %[v3]\n\t"
-        "s_mov_b64 exec, %[mB]\n\t"
-        "v_add_u32 %[a3], %[a3], %[dl]\n\t"
-        "ds_write_b32 %[d], %[w0]\n\t"
-        "ds_write_b32 %[a3], %[w1]\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [dl] "=&v"(dl), [w0] "=&v"(w0), [w1] "=&v"(w1), [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3),
-          [sv] "=&s"(sv), [mA] "=&s"(mA), [mB] "=&s"(mB)
-        : [d] "v"(d), [s] "v"(s), [n] "v"(n), [who] "s"(who)
-        : "vcc", "memory");
-}
-// Literal run of n = 1..64 bytes, staged chunk -> ring, neither range wrapping (the source may be read up to 7 bytes beyond its
-// end: still LDS): 8 and more as above; 1..7 from the 8 bytes at the source, written as 4 + 2 + 1 bytes by the bits of n.
-__device__ __forceinline__ void put_small_lds_1rt(uint32_t d, uint32_t s, uint32_t n, unsigned long long who) {
-    uint32_t a1, a2, a3, dl, dd, wl, wh; uint64_t v0, v1, v2, v3; unsigned long long sv, mA, mB, mT;
-    asm volatile(
-        "s_mov_b64 %[sv], exec\n\t"
-        "s_and_b64 exec, exec, %[who]\n\t"
-        "v_sub_u32 %[dl], %[d], %[s]\n\t"
-        "v_cmp_gt_u32 vcc, 8, %[n]\n\t"                       /* n < 8 */
-        "s_and_b64 %[mB], exec, vcc\n\t"
-        "s_andn2_b64 %[mA], exec, vcc\n\t"
-        "s_mov_b64 exec, %[mB]\n\t"
-        "ds_read_b32 %[wl], %[s]\n\t"
-        "ds_read_b32 %[wh], %[s] offset:4\n\t"
-        "v_mov_b32 %[dd], %[d]\n\t"
-        "s_mov_b64 exec, %[mA]\n\t"
-        "v_cmp_lt_u32 vcc, 16, %[n]\n\t"
-        "v_cndmask_b32_e64 %[a1], 0, 8, vcc\n\t"
-        "v_add_u32 %[a1], %[a1], %[s]\n\t"
-        "v_min_u32 %[a2], 32, %[n]\n\t"
-        "v_add3_u32 %[a3], %[s], %[a2], -8\n\t"
-        "v_add_u32 %[a2], -8, %[a3]\n\t"
-        "v_cndmask_b32 %[a2], %[s], %[a2], vcc\n\t"
-        "ds_read_b64 %[v0], %[s]\n\t"
-        "ds_read_b64 %[v1], %[a1]\n\t"
-        "ds_read_b64 %[v2], %[a2]\n\t"
-        "ds_read_b64 %[v3], %[a3]\n\t"
-        "v_add_u32 %[a1], %[a1], %[dl]\n\t"
-        "v_add_u32 %[a2], %[a2], %[dl]\n\t"
-        "v_add_u32 %[a3], %[a3], %[dl]\n\t"
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "ds_write_b64 %[d], %[v0]\n\t"
-        "ds_write_b64 %[a1], %[v1]\n\t"
-        "ds_write_b64 %[a2], %[v2]\n\t"
-        "ds_write_b64 %[a3], %[v3]\n\t"
-        /* 1..7 bytes: 4, then 2, then 1 */
-        "s_mov_b64 exec, %[mB]\n\t"
-        "v_and_b32 %[a1], 4, %[n]\n\t"
-        "v_cmp_ne_u32 vcc, 0, %[a1]\n\t"
-        "s_and_b64 %[mT], exec, vcc\n\t"
-        "s_mov_b64 exec, %[mT]\n\t"
-        "ds_write_b32 %[dd], %[wl]\n\t"
-        "v_mov_b32 %[wl], %[wh]\n\t"
-        "v_add_u32 %[dd], 4, %[dd]\n\t"
-        "s_mov_b64 exec, %[mB]\n\t"
-        "v_and_b32 %[a1], 2, %[n]\n\t"
-        "v_cmp_ne_u32 vcc, 0, %[a1]\n\t"
-        "s_and_b64 %[mT], exec, vcc\n\t"
-        "s_mov_b64 exec, %[mT]\n\t"
-        "ds_write_b16 %[dd], %[wl]\n\t"
-        "v_lshrrev_b32 %[wl], 16, %[wl]\n\t"
-        "v_add_u32 %[dd], 2, %[dd]\n\t"
-        "s_mov_b64 exec, %[mB]\n\t"
-        "v_and_b32 %[a1], 1, %[n]\n\t"
-        "v_cmp_ne_u32 vcc, 0, %[a1]\n\t"
-        "s_and_b64 %[mT], exec, vcc\n\t"
-        "s_mov_b64 exec, %[mT]\n\t"
-        "ds_write_b8 %[dd], %[wl]\n\t"
-        "s_mov_b64 exec, %[sv]"
-        : [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3), [dl] "=&v"(dl), [dd] "=&v"(dd), [wl] "=&v"(wl), [wh] "=&v"(wh), [v0] "=&v"(v0), [v1] "=&v"(v1), [v2] "=&v"(v2), [v3] "=&v"(v3),
-          [sv] "=&s"(sv), [mA] "=&s"(mA), [mB] "=&s"(mB), [mT] "=&s"(mT)
-        : [d] "v"(d), [s] "v"(s), [n] "v"(n), [who] "s"(who)
-        : "vcc", "memory");
-}
-
 struct No { static constexpr bool value = false; };
 struct Yes { static constexpr bool value = true; };
 }  // namespace
