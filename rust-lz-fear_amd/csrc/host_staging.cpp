@@ -145,7 +145,8 @@ uint8_t* Staging::pinned(size_t bytes) {
     if (bytes <= pin_cap_ && pin_) return pin_;
     if (pin_) { if (!drain_slots()) return nullptr; (void)hipHostFree(pin_); pin_ = nullptr; pin_cap_ = 0; }
     // (small calls pin little: 1 MiB steps below 16 MiB, 64 MiB steps beyond)
-    const size_t cap = round_up(bytes ? bytes : 1, bytes < (16u << 20) ? (1u << 20) : (64u << 20));
+    size_t cap = round_up(bytes ? bytes : 1, bytes < (16u << 20) ? (1u << 20) : (64u << 20));
+    { const size_t lim = ring_max_ ? ring_max_ : kRingMax; if (cap > lim && bytes <= lim) cap = lim; }      // (the growth step does not carry the slab over its limit)
     void* p = nullptr;
     if (hipHostMalloc(&p, cap, hipHostMallocDefault) != hipSuccess) return nullptr;
     pin_ = static_cast<uint8_t*>(p); pin_cap_ = cap;

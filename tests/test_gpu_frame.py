@@ -668,7 +668,8 @@ def test_decompress_many_memory_budget_slices_and_refuses():
 def test_many_frames_through_a_pinned_ring_smaller_than_the_call():
     """host_staging.cpp: a pass that moves more than the pinned slab may hold goes through it as a ring of 4 MiB slots (a slot is
     reused when the DMA that last read it has finished).  With the slab limited to 12 MiB — three slots — 24 frames (72 MiB in,
-    every payload and every decoded byte out) make the ring go round many times in both directions: frames == the oracle's,
+    every payload and every decoded byte out) make the ring go round many times in both directions (and once more with a 16 MiB limit, where
+    the slab's growth step of 64 MiB used to carry it over the limit): frames == the oracle's,
     round trip exact, linked frames and dictionary frames (their own layouts of the slab) included, small frames (the inline
     path borrows a slot too) in between, and the pinned footprint stays at the limit."""
     from rust_lz_fear_amd import ffi
@@ -688,6 +689,10 @@ def test_many_frames_through_a_pinned_ring_smaller_than_the_call():
             back = framed.decompress_frames(got, dictionary=kw.get("dictionary", b""), caps=[len(d) + 64 for d in datas])
             assert back == [(0, d) for d in datas], kw
             assert 0 < ffi.frame_stats()["pinned_bytes"] <= 12 << 20
+        ffi.lib().lzf_frame_set_pinned_limit(16 << 20)
+        cs = framed.CompressionSettings().block_size(256 << 10)
+        assert cs.compress_many(datas) == [o.frame_compress(d, o.make_settings(block_size=256 << 10))[1] for d in datas]
+        assert 0 < ffi.frame_stats()["pinned_bytes"] <= 16 << 20
     finally:
         ffi.lib().lzf_frame_set_pinned_limit(0)
         ffi.lib().lzf_frame_release_scratch()
