@@ -676,7 +676,11 @@ int lzf_decompress_batch_sized(const lzf_decompress_job* d_jobs, lzf_job_result*
     // (smaller LDS footprint, more blocks in flight); batches of more than eight times that many blocks (small blocks,
     // typically) go to the one-wave staged16 kernel, which has no per-block pipeline to fill.
     const uint32_t resident48 = per_cu(20u * 1024u) * cu_count();      // workgroups of the 48-byte form one device holds (20 KB of LDS each: 8 per CU on MI355X)
-    bool fed_on = n_jobs > resident48;
+    // the bitmap-fed path beyond what the 24-byte pair kernel holds at once (12.5 KiB of LDS per pair: 13 per CU, 3 328 on MI355X): up to
+    // there every block has its pair of wavefronts for itself and the pair kernel is quicker (2 107 jobs 30.5 against 36.0 ms, 3 038 jobs 34.0
+    // against 38.0; 4 214 jobs 51.1 against 46.1, 8 085 jobs 81.6 against 73.5: profiles/r06_fed_kernel_study.txt)
+    const uint32_t resident24 = per_cu(12800u) * cu_count();
+    bool fed_on = n_jobs > resident24;
 #ifdef LZF_ANALYSIS
     { static const int mode = [] { const char* e = getenv("LZF_DECOMPRESS_KERNEL"); return !e ? 0 : !strcmp(e, "fed") ? 1 : !strcmp(e, "nofed") ? 2 : 0; }();
       if (mode == 1) fed_on = true;

@@ -1,7 +1,7 @@
 """The dispatch thresholds are functions of the device's compute units and LDS (capi.hip `geometry()`), not literals: with the analysis
 knob LZF_FAKE_CU=64 the same device dispatches as one with 64 CUs — the segmented pipeline up to 4 x 64 blocks with rings of 128 / 64 /
-32 KiB at 64 / 128 / 256 blocks, paired48 up to 8 x 64, the bitmap-fed kernel beyond (round 6; paired24 / staged16 behind it when it
-declines a call) — and every class still decodes to the oracle's bytes.  Run as a script by tests/test_gpu_hardening.py (the knob is read once per process)."""
+32 KiB at 64 / 128 / 256 blocks, paired48 up to 8 x 64, paired24 up to 12 x 64, the bitmap-fed kernel beyond (round 6; paired24 /
+staged16 behind it when it declines a call) — and every class still decodes to the oracle's bytes.  Run as a script by tests/test_gpu_hardening.py (the knob is read once per process)."""
 import os
 import sys
 
@@ -24,7 +24,7 @@ def main():
     seen = {}
     # more compute units than the pipeline's rank kernels take jobs (one 1024-thread workgroup, capi.hip kSegRankMax): with
     # LZF_FAKE_CU=512 the pipeline's limit is 1024 jobs, not 4 x 512 — 1000 jobs go through it, 1500 go to the pair kernel
-    sizes = (1000, 1500) if cu > 256 else (cu - 4, cu + 4, 2 * cu + 4, 4 * cu - 4, 4 * cu + 8, 8 * cu + 8, 64 * cu + 16)
+    sizes = (1000, 1500) if cu > 256 else (cu - 4, cu + 4, 2 * cu + 4, 4 * cu - 4, 4 * cu + 8, 8 * cu + 8, 13 * cu + 8, 64 * cu + 16)
     for n in sizes:
         raws, comps = [], []
         for i in range(n):
@@ -45,7 +45,7 @@ def main():
         print("geometry ok")
         return
     want = {cu - 4: "resolve_pair_kernel<131072>", cu + 4: "resolve_pair_kernel<65536>", 2 * cu + 4: "resolve_pair_kernel<32768>", 4 * cu - 4: "resolve_pair_kernel<32768>",
-            4 * cu + 8: "lzf_decompress_paired_kernel<4096,48,640>", 8 * cu + 8: "bitmap-fed", 64 * cu + 16: "bitmap-fed"}
+            4 * cu + 8: "lzf_decompress_paired_kernel<4096,48,640>", 8 * cu + 8: "lzf_decompress_paired_kernel<4096,24,384>", 13 * cu + 8: "bitmap-fed", 64 * cu + 16: "bitmap-fed"}
     for n, frag in want.items():
         assert frag in seen[n], (n, seen[n], frag)
         if "resolve" not in frag:
