@@ -380,14 +380,26 @@ int seg_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, 
 // 13.0 of its 27.8 wave-instructions per sequence, the hop parse 3.8 — then the pair kernel over whatever that left (errors,
 // sizes outside the map's window, a chain that did not verify).
 constexpr auto k_fed32 = lzf::lzf_decompress_fed_kernel<4096, 32, 352>;
-constexpr uint32_t kFedMinInDefault = 65536u;                        // smaller inputs are left to the pair kernel: per job the feed costs a census of pieces, a chunk's parse and a ring
-                                                                     // re-fill — 16 384 jobs of ~32 KiB ran at 380 GiB/s through it and at 484 through the pair kernel (bench config5, u16_raw)
+constexpr uint32_t kFedMinInDefault = 65536u;                        // per job: smaller inputs are left to the pair kernel behind the fed kernel
+// per call: a caller that bounds its inputs (lzf_decompress_batch_sized, the frame layer) keeps batches of small blocks off this path
+// altogether — per job the feed costs a census of pieces, a chunk's parse and a ring re-fill: 16 384 jobs of ~32 KiB ran at 380 GiB/s
+// through it and at 484 through the pair kernel (bench config5, u16_raw); 18 000 blocks of 256 KiB (inputs ~128 KiB) 12.97 against
+// 12.43 ms; 4 536 blocks of 1 MiB 12.72 against 14.05.  (The bound is the call's, not the job's: with the small inputs of a batch of
+// large blocks left to a second kernel behind the first, the 1 MiB call took 18.2 ms.)
+constexpr uint64_t kFedMinHint = 262144u;
 inline uint32_t fed_min_in() {
 #ifdef LZF_ANALYSIS      // LZF_FED_MIN_IN: the smallest input the bitmap-fed kernel takes (the variant parity test opens it to every input)
     static const long v = [] { const char* e = getenv("LZF_FED_MIN_IN"); return e ? atol(e) : -1L; }();
     if (v >= 0) return (uint32_t)v;
 #endif
     return kFedMinInDefault;
+}
+inline uint64_t fed_min_hint() {
+#ifdef LZF_ANALYSIS      // (LZF_FED_MIN_IN opens the path to every call as well: the variant parity test)
+    static const bool open_ = getenv("LZF_FED_MIN_IN") != nullptr;
+    if (open_) return 0u;
+#endif
+    return kFedMinHint;
 }
 constexpr uint64_t kFedMaxScratch = 24ull << 30;                     // bit maps of a call: 1 bit per compressed byte of the largest job x jobs (16 / 14 with the chunks' overlap)
 constexpr uint32_t kFedMaxJobs = 65535u;                             // (the chunk stage's grid has one row per job)
@@ -502,7 +514,7 @@ int fed_back(FedCall& f, hipStream_t st, uint32_t slots_per_cu) {
 }
 int fed_decompress(const lzf_decompress_job* d_jobs, lzf_job_result* d_results, uint32_t n, const uint32_t* perm, hipStream_t st, bool* used, uint64_t max_in_hint) {
     *used = false;
-    if (n > kFedMaxJobs || max_in_hint <= fed_min_in()) return LZF_OK;   // (a caller that bounds its inputs — lzf_decompress_batch_sized, the frame layer — spares small-block batches the empty launches)
+    if (n > kFedMaxJobs || max_in_hint <= fed_min_in() || max_in_hint <= fed_min_hint()) return LZF_OK;
     FedCall f;
     int rc = fed_front(f, d_jobs, d_results, n, perm, st, max_in_hint);
     if (rc != LZF_OK || !f.live) return rc;

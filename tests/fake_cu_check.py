@@ -18,9 +18,9 @@ def main():
     cu = int(os.environ["LZF_FAKE_CU"])
     rng = np.random.default_rng(8)
     base = synth.silesia_mix(0, 2 << 20)
-    big = [synth.silesia_mix(k << 20, (k << 20) + 300000).tobytes() for k in (1, 9, 30, 50)]      # >= 64 KiB compressed: the pipeline's window
+    big = [synth.silesia_mix(k << 20, (k << 20) + 900000).tobytes() for k in (1, 9, 30, 50)]      # >= 256 KiB compressed: the pipeline's window (64 KiB) and the bitmap-fed kernel's (256 KiB)
     bigc = [o.compress2(d)[1] for d in big]
-    assert all(len(c) >= 65536 for c in bigc)
+    assert all(len(c) > 262144 for c in bigc), [len(c) for c in bigc]
     seen = {}
     # more compute units than the pipeline's rank kernels take jobs (one 1024-thread workgroup, capi.hip kSegRankMax): with
     # LZF_FAKE_CU=512 the pipeline's limit is 1024 jobs, not 4 x 512 — 1000 jobs go through it, 1500 go to the pair kernel

@@ -118,7 +118,7 @@ def test_redzone_bitmap_fed_kernel_and_its_hand_over():
     base = synth.silesia_mix(0, 24 << 20)
     raws, comps = [], []
     for i in range(60):
-        a = int(rng.integers(0, (24 << 20) - 300000)); ln = int(rng.choice([3000, 20000, 70000, 150000, 260000]))
+        a = int(rng.integers(0, (24 << 20) - 300000)); ln = int(rng.choice([3000, 20000, 70000, 150000, 260000, 800000]))
         d = base[a:a + ln].tobytes(); raws.append(d); comps.append(o.compress2(d)[1])
     n_jobs = 3300
     items, exp = [], []
