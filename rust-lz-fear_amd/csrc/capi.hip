@@ -573,8 +573,10 @@ int lzf_compress_batch(const lzf_compress_job* d_jobs, lzf_job_result* d_results
     // the cost of a compress job is not known from its size: probe (aux_kernels.hip), then longest first
     // (from four jobs per CU on — not only beyond the 18 per CU the chip holds at once: the order also spreads the expensive blocks over the
     //  compute units of a launch that is resident as a whole; one call over N four-MiB blocks, caller's order against longest first, probe
-    //  included: 1 020 blocks 287 / 286 ms, 2 040 338 / 293, 3 060 420 / 305, 3 825 440 / 339, 4 590 488 / 357)
-    const bool want_order = use_order && use_compact && (table_kinds & LZF_KINDS_U32) && (use_order == 2u || n_jobs > 4u * cu_count());
+    //  included: 1 020 blocks 287 / 286 ms, 2 040 338 / 293, 3 060 420 / 305, 3 825 440 / 339, 4 590 488 / 357.  Below one residency only for
+    //  calls that vouch for fresh tables — every job then is the probe's kind of job; a call of carried tables is typically thousands of
+    //  64 KiB blocks of linked streams, too small to be probed, for which the three extra launches were 15 % of the call: bench config5)
+    const bool want_order = use_order && use_compact && (table_kinds & LZF_KINDS_U32) && (use_order == 2u || n_jobs > per_cu(lzf::kCompactLdsBytes) * cu_count() || (fresh_only && n_jobs > 4u * cu_count()));
     uint32_t piece = 65536u, parts = 1u;            // one 64 KiB piece from the middle of each payload (more or smaller pieces order no better)
 #ifdef LZF_ANALYSIS      // LZF_PROBE="piece,parts": the cost probe's sample (A/B of the launch order's estimate)
     { static const char* e = getenv("LZF_PROBE"); if (e) { unsigned a = 0, b = 0; if (sscanf(e, "%u,%u", &a, &b) == 2 && a >= 4096u && b >= 1u && b <= 16u) { piece = a; parts = b; } } }
